@@ -1,0 +1,187 @@
+/* yv_hip.h - C ABI of the MI355X (gfx950) hot-path library `libyvhip.so`.
+ *
+ * Drop-in boundary of the detect -> NMS/inflate/crop -> ViT-classify path of
+ * Voyager0587/yolov8-vit.  The reference has NO native/FFI interface (SURVEY.md
+ * section 8(b)): its boundary is a Python call surface.  Each entry point below
+ * therefore cites the reference *Python site* whose arithmetic it replaces; the
+ * Python host side (yolov8-vit_amd/) binds these symbols with ctypes and mirrors
+ * the reference's names.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on
+ *    it (no allocation, no synchronisation, graph-capturable);
+ *  - the caller owns all buffers, including `ws` workspaces whose minimum size
+ *    is returned by the matching `*_ws_bytes` function;
+ *  - return value: 0 = YV_OK, negative = error (yv_error_string), never throws;
+ *  - bf16 tensors are raw uint16_t storage; "NHWC view" = base pointer + pixel
+ *    stride `ld` in elements (lets producers write straight into concat
+ *    buffers and consumers read channel slices: no concat/split kernels).
+ */
+#ifndef YV_HIP_H
+#define YV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YV_OK 0
+#define YV_ERR_ARG (-1)        /* bad size / null pointer / unsupported shape */
+#define YV_ERR_LIMIT (-2)      /* exceeds a documented kernel limit           */
+#define YV_ERR_WORKSPACE (-3)  /* workspace too small                          */
+#define YV_ERR_LAUNCH (-4)     /* hipLaunch failed (hipGetLastError != 0)     */
+
+int yv_version(void);
+const char* yv_error_string(int code);
+/* 1 if the current HIP device is gfx950, 0 otherwise, <0 on HIP error. */
+int yv_device_is_gfx950(void);
+
+/* ------------------------------------------------------------------ boxes */
+
+/* custom_nms(boxes, scores, iou_threshold=0.45)  -- README.md:62-84 (== tech.md:72-94).
+ * Class-agnostic greedy NMS, strict `<`, returns ORIGINAL indices in
+ * (score desc, index asc) order.  Batched: set s uses rows [s*n_max, s*n_max+count[s]).
+ * boxes (S,n_max,4) f32 xyxy; scores (S,n_max) f32; counts (S) i32 or NULL (= n_max);
+ * keep (S,n_max) i32 (tail filled with -1); num_keep (S) i32.  n_max <= 16384. */
+size_t yv_custom_nms_ws_bytes(int n_sets, int n_max);
+int yv_custom_nms(const float* boxes, const float* scores, const int32_t* counts, int n_sets, int n_max,
+                  float iou_threshold, int32_t* keep, int32_t* num_keep, void* ws, size_t ws_bytes, void* stream);
+
+/* EfficientNMS_TRT output contract -- tech.md:41-47, test.ipynb:20-24 (KAT-2).
+ * boxes (B,A,4) f32 xyxy; scores (B,A,nc) f32 (already sigmoid).  Outputs:
+ * num_dets (B,1) i32, out_boxes (B,max_out,4) f32, out_scores (B,max_out) f32,
+ * out_labels (B,max_out) i32, zero padded, sorted by score.  pre_topk <= 4096. */
+int yv_efficient_nms(const float* boxes, const float* scores, int B, int A, int nc, float score_threshold,
+                     float iou_threshold, int max_out, int pre_topk, int32_t* num_dets, float* out_boxes,
+                     float* out_scores, int32_t* out_labels, void* stream);
+
+/* det_postprocess + coordinate restore + score filter + int cast
+ * (YOLOTensorRT_yolodet_py_解读.md:82-99), then custom_nms dedupe (README.md:41,62-84),
+ * then crop_image's integer inflate/clamp (utils/trainClass.py:70-93, eval branch).
+ * Per image b: ratio[b], dwdh[b] (2 f32), img_wh[b] (2 i32: original width,height).
+ * coord_mode 0 = trunc toward zero (Python int()), 1 = round-half-even then int.
+ * Outputs per image (slots = max_out of the NMS stage, e.g. 100):
+ *   det_count (B) i32            number of reported detections (score order)
+ *   det_box (B,slots,4) i32      xmin,ymin,xmax,ymax in original-image pixels
+ *   det_score (B,slots) f32, det_label (B,slots) i32
+ *   crop_rect (B,slots,4) i32    inflated+clamped rect (x0,y0,x1,y1), right/bottom exclusive
+ *   crop_ok (B,slots) i32        0 when the rect is degenerate (PIL would raise)
+ * max_crops: cap of detections kept per image (<=0: no cap).                 */
+int yv_postprocess_dets(const int32_t* num_dets, const float* bboxes, const float* scores, const int32_t* labels,
+                        int B, int slots, const float* ratio, const float* dwdh, const int32_t* img_wh,
+                        float conf_threshold, float dedupe_iou, int coord_mode, int max_crops,
+                        int32_t* det_count, int32_t* det_box, float* det_score, int32_t* det_label,
+                        int32_t* crop_rect, int32_t* crop_ok, void* stream);
+
+/* Device-side compaction of the per-image crop lists into one batch:
+ * crop_list (cap,6) i32 rows {image, x0, y0, x1, y1, slot}; crop_total (1) i32.
+ * Order: image ascending, then detection (score) order.  Rows >= total are zeroed. */
+int yv_compact_crops(const int32_t* det_count, const int32_t* crop_rect, const int32_t* crop_ok, int B, int slots,
+                     int cap, int32_t* crop_list, int32_t* crop_total, void* stream);
+
+/* crop + A.Resize(224,224,INTER_NEAREST) + A.Normalize(.5,.5) + HWC->CHW
+ * (utils/trainClass.py:92,218-221,265-266; app.py:39-42).
+ * images: (B,H,W,3) u8 RGB with per-image byte stride img_stride; crop_list as above;
+ * crop_total: device i32 (NULL = all `cap` rows valid).
+ * layout 0: out = (cap,3,S,S) f32 CHW     layout 1: out = (cap,3,S,S) bf16 CHW
+ * layout 2: out = (cap*(S/P)^2, 3*P*P) bf16 patch-major rows (col = c*P*P + py*P + px),
+ *           the A operand of the patch-embed GEMM.  S = out_size (224), P = patch. */
+int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, size_t img_stride, const int32_t* crop_list,
+                        const int32_t* crop_total, int cap, int out_size, int patch, int layout, void* out,
+                        void* stream);
+
+/* DFL decode + anchors + sigmoid (docs/YOLO_TensorRT_Technical.md:14-30,72-77).
+ * Per scale s (3 scales, strides 8/16/32): box logits (B,Hs,Ws,64) f32 and class
+ * logits (B,Hs,Ws,cls_ld) f32, NHWC.  Outputs boxes (B,A,4) f32 xyxy input pixels,
+ * scores (B,A,nc) f32; anchor order = scale, then y*W+x. */
+int yv_detect_decode(const float* box0, const float* box1, const float* box2, const float* cls0, const float* cls1,
+                     const float* cls2, int cls_ld, int B, int size, int nc, float* boxes, float* scores,
+                     void* stream);
+
+/* ------------------------------------------------------------ dense math */
+
+/* Operand view for the implicit-GEMM kernel: NHWC bf16 tensor slice.
+ * up = 1: the tensor is read through a nearest 2x upsample (K4). */
+typedef struct yv_view {
+    const void* ptr; /* bf16 */
+    int ld;          /* elements between consecutive pixels */
+    int c;           /* channels read from this view        */
+    int up;          /* 0 | 1                               */
+} yv_view;
+
+/* epilogue flags */
+#define YV_EPI_BIAS 1
+#define YV_EPI_SILU 2
+#define YV_EPI_GELU 4       /* exact erf GELU */
+#define YV_EPI_RES_F32 8    /* out_f32 += (read-modify-write residual stream) */
+#define YV_EPI_RES_BF16 16  /* + bf16 residual view (Bottleneck shortcut)     */
+#define YV_EPI_OUT_F32 32   /* store f32 instead of bf16                      */
+#define YV_EPI_POSEMB 64    /* patch-embed row remap + pos_embed add          */
+
+/* Conv2d(k in {1,3}, stride in {1,2}, pad k/2) + folded-BN bias + SiLU as an
+ * implicit GEMM on MFMA (ultralytics Conv/C2f/SPPF/Detect convs; structure per
+ * docs/YOLO_TensorRT_Technical.md:160-212, fusion per test.ipynb:25,1285).
+ * in0 (+ optional in1 = channel concat, 1x1 only) are (B,Hin,Win,*) views;
+ * weight (Cout, k*k*Cin) bf16 with K order (ky,kx,cin); bias (Cout) f32;
+ * out = (B,Hout,Wout,*) view with pixel stride out_ld (bf16, or f32 with YV_EPI_OUT_F32);
+ * res = optional bf16 residual view (same pixel grid as out). */
+int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
+              const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res, int res_ld,
+              int flags, void* stream);
+
+/* Linear: out[M,N] = A[M,K] @ W[N,K]^T (+bias)(+GELU)(+residual) on MFMA
+ * (timm Attention.qkv/proj, Mlp.fc1/fc2, head; README.md:21-35).
+ * A (M,K) bf16 row stride lda; W (N,K) bf16; bias (N) f32.
+ * m_dev: optional device i32 overriding M at run time (tiles beyond it exit).
+ * YV_EPI_POSEMB: row m -> out row (m/tok)*(tok+1)+1+(m%tok), adds pos[(1+m%tok)*N + n]. */
+int yv_linear(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out, int ldo,
+              const float* pos, int tok, int flags, const int32_t* m_dev, void* stream);
+
+/* LayerNorm over the last dim (timm blocks.*.norm1/2, norm; eps 1e-6; README.md:21-29).
+ * x (rows, D) f32 with row stride ldx -> y (rows, D) bf16 row stride ldy. */
+int yv_layernorm(const float* x, size_t ldx, const float* gamma, const float* beta, int rows, int D, float eps,
+                 void* y, size_t ldy, const int32_t* rows_dev, void* stream);
+
+/* Fused attention forward, non-causal: softmax(Q K^T * scale) V (timm Attention; README.md:21-23).
+ * qkv (R*N, 3*H*64) bf16 as produced by the qkv Linear ([q|k|v], head-major);
+ * out (R*N, H*64) bf16.  head dim 64; N <= 256 per pass (ViT-x/16: 197). */
+int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev, void* stream);
+
+/* cls rows of the token stream: x[r*(tok+1), :] = cls + pos[0]  (timm cls_token + pos_embed) */
+int yv_cls_rows(const float* cls, const float* pos, int R, int tok, int D, float* x, void* stream);
+
+/* Network_Wrapper.fc on backbone logits + argmax (utils/utils.py:64-72, utils/trainClass.py:112):
+ * feats (R, ldf) f32 (first 1000 used) -> logits (R,nc) f32 [accumulated when accumulate!=0,
+ * scaled by `scale`: mean-of-logits ensemble over model_list], labels (R) i32 (argmax, first max). */
+int yv_wrapper_head(const float* feats, int ldf, const float* w1, const float* b1, const float* w2, const float* b2,
+                    int R, int nc, float scale, int accumulate, float* logits, int32_t* labels,
+                    const int32_t* r_dev, void* stream);
+
+/* SPPF: three chained 5x5/s1/p2 max-pools (== windows 5/9/13) in one pass (model.9).
+ * buf: (B,H,W,ld) bf16; reads channels [0,c), writes [c,2c), [2c,3c), [3c,4c). */
+int yv_sppf_pool(void* buf, int B, int H, int W, int ld, int c, void* stream);
+
+/* Stem: blob (u8 RGB /255, 解读.md:70-74) + Conv 3x3 s2 + bias + SiLU (model.0).
+ * images (B,H,W,3) u8; weight (Cout,27) f32 K order (ky,kx,c); out (B,H/2,W/2,Cout) bf16, ld = out_ld. */
+int yv_stem_conv(const uint8_t* images, int B, int H, int W, const float* weight, const float* bias, int Cout,
+                 void* out, int out_ld, void* stream);
+
+/* ------------------------------------------------------------- training */
+
+/* build_loss = LSCE(0.1)/6 + Focal(1,2,'mean')*5/6 (utils/trainClass.py:46-66,162-185,362-370)
+ * logits (B,nc) f32, labels (B) i32 -> loss (1) f32, grad (B,nc) f32 (d loss / d logits). */
+int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, float* loss, float* grad,
+                    void* stream);
+
+/* torch.optim.SGD(momentum, weight_decay) step (utils/trainClass.py:442-443), fp32, in place:
+ * g += wd*p; m = first ? g : mu*m + g; p -= lr*m. */
+int yv_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum, float weight_decay,
+                int first, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YV_HIP_H */

@@ -1,0 +1,274 @@
+"""GPU parity: NMS family, postprocess, crop gather, decode, loss, SGD vs the oracle
+and the golden fixtures.  Bit-exact for indices / integer coordinates / f32 gathers."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from inputs import coord_image, seeded_boxes
+from oracle import boxes as ob
+from oracle import train as ot
+from oracle import yolo as oy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def yv():
+    import yvhip
+    yvhip.require_gpu()
+    assert yvhip.lib.yv_device_is_gfx950() == 1
+    return yvhip
+
+
+DEV = "cuda:0"
+
+
+# ------------------------------------------------------------------ custom_nms
+def test_custom_nms_golden(yv, golden):
+    for c in golden["G7_custom_nms"]:
+        if "explicit_boxes" in c:
+            b, s = torch.tensor(c["explicit_boxes"]), torch.tensor(c["scores"])
+        elif c["n"] == 0:
+            b, s = torch.zeros(0, 4), torch.zeros(0)
+        else:
+            b, s = seeded_boxes(c["n"], c["seed"])
+        assert yv.custom_nms(b, s, c["thr"]) == c["keep"], (c.get("n"), c["thr"])
+
+
+def test_custom_nms_ties_and_degenerate(yv):
+    # exact score ties -> (score desc, index asc), identical to the oracle's stable sort
+    g = torch.Generator().manual_seed(1)
+    b, _ = seeded_boxes(300, 21)
+    s = torch.randint(0, 8, (300,), generator=g).float() / 8
+    assert yv.custom_nms(b, s, 0.45) == ob.custom_nms(b, s, 0.45)
+    # zero-area boxes: 0/0 IoU is NaN -> never "< thr" -> suppressed, like the reference mask
+    b = torch.tensor([[1., 1., 1., 1.], [1., 1., 1., 1.], [0., 0., 4., 4.]])
+    s = torch.tensor([.9, .8, .7])
+    assert yv.custom_nms(b, s, 0.45) == ob.custom_nms(b, s, 0.45) == [0, 2]
+    # negative zero / negative scores ordering
+    s = torch.tensor([-0.0, 0.0, -1.0])
+    b = torch.tensor([[0., 0., 1., 1.], [10., 10., 11., 11.], [20., 20., 21., 21.]])
+    assert yv.custom_nms(b, s, 0.45) == ob.custom_nms(b, s, 0.45) == [0, 1, 2]
+
+
+def test_custom_nms_batched_ragged(yv):
+    S, n = 37, 100
+    bs, ss, counts = [], [], []
+    rng = random.Random(3)
+    for i in range(S):
+        b, s = seeded_boxes(n, 100 + i)
+        bs.append(b); ss.append(s); counts.append(rng.choice([0, 1, 2, 17, 64, 65, 100]))
+    B = torch.stack(bs).to(DEV); Sc = torch.stack(ss).to(DEV)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    keep, num = yv.custom_nms_batched(B, Sc, cnt, 0.45)
+    keep, num = keep.cpu(), num.cpu()
+    for i in range(S):
+        exp = ob.custom_nms(bs[i][:counts[i]], ss[i][:counts[i]], 0.45)
+        assert int(num[i]) == len(exp) and keep[i, :len(exp)].tolist() == exp
+        assert torch.all(keep[i, len(exp):] == -1)
+
+
+def test_custom_nms_full_size_properties(yv):
+    # BASELINE-size property checks: idempotence, sortedness, mutual IoU < thr (n = 8400 raw anchors)
+    b, s = seeded_boxes(8400, 99)
+    keep = yv.custom_nms(b, s, 0.45)
+    kb, ks = b[keep], s[keep]
+    assert torch.all(ks[:-1] >= ks[1:])
+    assert yv.custom_nms(kb, ks, 0.45) == list(range(len(keep)))
+    iou = ob.box_iou(kb, kb)
+    iou.fill_diagonal_(0)
+    assert float(iou.max()) < 0.45
+
+
+# ------------------------------------------------------------------ EfficientNMS contract
+def _rand_dets(B, A, nc, seed, dense=False):
+    g = torch.Generator().manual_seed(seed)
+    boxes = torch.stack([seeded_boxes(A, seed * 131 + i)[0] for i in range(B)])
+    if dense:
+        scores = torch.rand(B, A, nc, generator=g)
+    else:
+        scores = torch.rand(B, A, nc, generator=g) ** 8
+    return boxes, scores
+
+
+@pytest.mark.parametrize("B,A,nc,dense", [(3, 500, 5, False), (2, 8400, 5, False), (2, 8400, 5, True), (1, 64, 1, True),
+                                          (2, 1000, 80, False)])
+def test_efficient_nms_vs_oracle(yv, B, A, nc, dense):
+    boxes, scores = _rand_dets(B, A, nc, 5 + A + nc, dense)
+    exp = ob.efficient_nms(boxes, scores)
+    got = yv.efficient_nms(boxes.to(DEV), scores.to(DEV))
+    for e, g in zip(exp, got):
+        assert torch.equal(e, g.cpu())
+
+
+def test_efficient_nms_ties_on_cut_and_empty(yv):
+    # many equal scores straddling the pre-NMS top-k cut: lowest flat index wins (defined behaviour)
+    B, A, nc = 1, 8400, 5
+    boxes, _ = _rand_dets(B, A, nc, 77)
+    g = torch.Generator().manual_seed(9)
+    scores = (torch.randint(0, 6, (B, A, nc), generator=g).float() / 8 + 0.3)
+    exp = ob.efficient_nms(boxes, scores)
+    got = yv.efficient_nms(boxes.to(DEV), scores.to(DEV))
+    for e, g_ in zip(exp, got):
+        assert torch.equal(e, g_.cpu())
+    # nothing above threshold -> zero detections, zero padded
+    got = yv.efficient_nms(boxes.to(DEV), torch.zeros(B, A, nc, device=DEV))
+    assert int(got[0][0, 0]) == 0 and float(got[1].abs().sum()) == 0 and float(got[2].abs().sum()) == 0
+
+
+# ------------------------------------------------------------------ postprocess + compaction
+def _oracle_post(num, bb, sc, lb, ratio, dwdh, wh, conf, thr, mode, cap):
+    idx, ib, s, l = ob.restore_and_filter(num, bb, sc, lb, ratio, dwdh, conf, mode)
+    n = int(num)
+    d = torch.tensor([dwdh[0], dwdh[1], dwdh[0], dwdh[1]], dtype=torch.float32)
+    fb = (bb[:n].float() - d) / torch.tensor(ratio, dtype=torch.float32)
+    sel = torch.tensor(idx, dtype=torch.long)
+    keep = ob.custom_nms(fb[sel], sc[:n][sel], thr) if len(idx) else []
+    if cap > 0:
+        keep = keep[:cap]
+    dets = []
+    for k in keep:
+        x0, y0, x1, y1 = ib[k]
+        rect = ob.inflate_eval(x0, y0, x1, y1, wh[0], wh[1])
+        dets.append((ib[k], s[k], l[k], list(rect), int(rect[2] > rect[0] and rect[3] > rect[1])))
+    return dets
+
+
+@pytest.mark.parametrize("mode", ["trunc", "round"])
+def test_postprocess_vs_oracle(yv, mode):
+    B, K = 9, 100
+    boxes, scores = _rand_dets(B, 2000, 5, 41)
+    num, bb, sc, lb = ob.efficient_nms(boxes, scores)
+    rng = random.Random(5)
+    ratio = [1.0, 0.5, 0.3333333, 0.75, 1.0, 0.6, 0.9, 0.41, 1.0]
+    dwdh = [(0.0, 0.0), (0.0, 80.0), (13.5, 0.0), (0.0, 40.0), (0.0, 0.0), (10.0, 0.0), (0.0, 3.5), (7.0, 9.0), (0., 0.)]
+    wh = [(640, 640), (1280, 960), (1839, 1920), (853, 746), (640, 640), (1033, 1066), (711, 703), (1526, 1517), (64, 48)]
+    num[4, 0] = 0                       # an image without detections
+    out = yv.postprocess_dets(num.to(DEV), bb.to(DEV), sc.to(DEV), lb.to(DEV),
+                              torch.tensor(ratio, device=DEV), torch.tensor(dwdh, device=DEV).reshape(-1),
+                              torch.tensor(wh, dtype=torch.int32, device=DEV).reshape(-1),
+                              conf=0.35, dedupe_iou=0.45, coord_mode=mode, max_crops=0)
+    out = {k: v.cpu() for k, v in out.items()}
+    total_exp = []
+    for b in range(B):
+        dets = _oracle_post(num[b, 0], bb[b], sc[b], lb[b], ratio[b], dwdh[b], wh[b], 0.35, 0.45, mode, 0)
+        assert int(out["det_count"][b]) == len(dets), b
+        for k, (ibox, s, l, rect, ok) in enumerate(dets):
+            assert out["det_box"][b, k].tolist() == ibox
+            assert float(out["det_score"][b, k]) == s and int(out["det_label"][b, k]) == l
+            assert out["crop_rect"][b, k].tolist() == rect and int(out["crop_ok"][b, k]) == ok
+            if ok:
+                total_exp.append([b] + rect + [k])
+    cl, tot = yv.compact_crops(out["det_count"].to(DEV), out["crop_rect"].to(DEV), out["crop_ok"].to(DEV), 1024)
+    assert int(tot[0]) == len(total_exp)
+    assert cl.cpu()[:len(total_exp)].tolist() == total_exp
+    # capacity smaller than the total truncates in order
+    cl2, tot2 = yv.compact_crops(out["det_count"].to(DEV), out["crop_rect"].to(DEV), out["crop_ok"].to(DEV), 5)
+    assert int(tot2[0]) == 5 and cl2.cpu().tolist() == total_exp[:5]
+
+
+def test_postprocess_inflate_golden(yv, golden):
+    """crop_image's inflate (G1) through the device kernel: one detection per 'image'."""
+    cases = [c for c in golden["G1_crop_eval"]]
+    B = len(cases)
+    bb = torch.zeros(B, 100, 4); sc = torch.zeros(B, 100); lb = torch.zeros(B, 100, dtype=torch.int32)
+    num = torch.ones(B, 1, dtype=torch.int32)
+    for i, c in enumerate(cases):
+        bb[i, 0] = torch.tensor(c["box"], dtype=torch.float32)
+        sc[i, 0] = 0.9
+    wh = torch.tensor([[c["W"], c["H"]] for c in cases], dtype=torch.int32)
+    out = yv.postprocess_dets(num.to(DEV), bb.to(DEV), sc.to(DEV), lb.to(DEV), torch.ones(B, device=DEV),
+                              torch.zeros(2 * B, device=DEV), wh.reshape(-1).to(DEV))
+    rect = out["crop_rect"].cpu(); ok = out["crop_ok"].cpu()
+    for i, c in enumerate(cases):
+        x0, y0, x1, y1 = rect[i, 0].tolist()
+        if "error" in c or c.get("empty"):
+            assert int(ok[i, 0]) == 0
+        else:
+            assert [x0, y0] == c["origin"] and [x1 - x0, y1 - y0] == c["size"] and int(ok[i, 0]) == 1
+
+
+def test_postprocess_max_crops_and_no_dedupe(yv):
+    boxes, scores = _rand_dets(2, 3000, 5, 8, dense=True)
+    num, bb, sc, lb = ob.efficient_nms(boxes, scores)
+    args = (num.to(DEV), bb.to(DEV), sc.to(DEV), lb.to(DEV), torch.ones(2, device=DEV), torch.zeros(4, device=DEV),
+            torch.tensor([640, 640, 640, 640], dtype=torch.int32, device=DEV))
+    o4 = yv.postprocess_dets(*args, max_crops=4)
+    o0 = yv.postprocess_dets(*args, max_crops=0)
+    assert o4["det_count"].tolist() == [4, 4]
+    assert torch.equal(o4["det_box"][:, :4], o0["det_box"][:, :4])
+    on = yv.postprocess_dets(*args, dedupe_iou=0.0)
+    assert on["det_count"].tolist() == [int((sc[b, :int(num[b, 0])] >= 0.35).sum()) for b in range(2)]
+
+
+# ------------------------------------------------------------------ crop gather
+def test_crop_resize_norm_bit_exact(yv):
+    W, H = 640, 480
+    g = torch.Generator().manual_seed(12)
+    imgs = torch.randint(0, 256, (3, H, W, 3), generator=g, dtype=torch.uint8)
+    imgs[0] = torch.from_numpy(coord_image(W, H))
+    rects = [(0, 78, 33, 298, 253, 0), (0, 0, 0, 38, 30, 1), (1, 598, 438, 640, 480, 0), (1, 5, 5, 16, 14, 1),
+             (2, 0, 0, 640, 480, 0), (2, 100, 100, 101, 101, 1), (2, 17, 3, 241, 227, 2), (0, 300, 200, 301, 480, 2)]
+    cl = torch.tensor(rects, dtype=torch.int32, device=DEV)
+    tot = torch.tensor([len(rects)], dtype=torch.int32, device=DEV)
+    dimg = imgs.to(DEV)
+    f32 = yv.crop_resize_norm(dimg, cl, tot, len(rects), 224, 16, layout=0).cpu()
+    b16 = yv.crop_resize_norm(dimg, cl, tot, len(rects), 224, 16, layout=1).cpu()
+    pm = yv.crop_resize_norm(dimg, cl, tot, len(rects), 224, 16, layout=2).cpu()
+    pm8 = yv.crop_resize_norm(dimg, cl, tot, len(rects), 224, 8, layout=2).cpu()
+    for r, rc in enumerate(rects):
+        exp = ob.crop_resize_normalize(imgs[rc[0]].numpy(), rc[1:5])
+        assert np.array_equal(f32[r].numpy(), exp), r                        # f32: bit exact
+        e16 = torch.from_numpy(exp).to(torch.bfloat16)
+        assert torch.equal(b16[r], e16)                                      # bf16: RNE of the same f32
+        assert torch.equal(pm[r * 196:(r + 1) * 196], torch.from_numpy(ob.patchify(exp, 16)).to(torch.bfloat16))
+        assert torch.equal(pm8[r * 784:(r + 1) * 784], torch.from_numpy(ob.patchify(exp, 8)).to(torch.bfloat16))
+    # rows beyond crop_total are untouched (device-side dynamic batch)
+    tot1 = torch.tensor([2], dtype=torch.int32, device=DEV)
+    part = yv.crop_resize_norm(dimg, cl, tot1, len(rects), 224, 16, layout=0).cpu()
+    assert torch.equal(part[:2], f32[:2]) and float(part[2:].abs().sum()) == 0
+
+
+# ------------------------------------------------------------------ decode
+def test_detect_decode_vs_oracle(yv):
+    B, nc, size = 2, 5, 640
+    g = torch.Generator().manual_seed(4)
+    raw = torch.randn(B, 64 + nc, 8400, generator=g) * 2
+    eb, es = oy.decode(raw, nc, size)
+    box_l, cls_l, a0 = [], [], 0
+    for s in (8, 16, 32):
+        w = size // s
+        part = raw[:, :, a0:a0 + w * w].reshape(B, 64 + nc, w, w).permute(0, 2, 3, 1).contiguous()
+        box_l.append(part[..., :64].contiguous().to(DEV))
+        c = torch.zeros(B, w, w, 8); c[..., :nc] = part[..., 64:]
+        cls_l.append(c.to(DEV))
+        a0 += w * w
+    gb, gs = yv.detect_decode(box_l, cls_l, size, nc)
+    # fp tolerance: exp() implementations differ; coordinates are O(100) px
+    assert torch.allclose(gb.cpu(), eb, atol=2e-3, rtol=1e-5)
+    assert torch.allclose(gs.cpu(), es, atol=1e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ loss / SGD
+def test_loss_golden(yv, golden):
+    for c in golden["G3_loss"]:
+        x = torch.tensor(c["x"], device=DEV); lab = torch.tensor(c["label"], dtype=torch.int32, device=DEV)
+        loss, grad = yv.loss_fwd_bwd(x, lab)
+        assert abs(float(loss[0]) - c["total"]) < 2e-6 * max(1.0, abs(c["total"]))      # f32 tolerance
+        assert torch.allclose(grad.cpu(), torch.tensor(c["grad"]), atol=1e-7, rtol=2e-5)
+
+
+def test_sgd_step_bit_exact(yv):
+    g = torch.Generator().manual_seed(2)
+    n = 1000003
+    p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g) * 0.01
+    pe, me = ot.sgd_step(p, gr, None, 1e-4)
+    pd, md = p.to(DEV), torch.zeros(n, device=DEV)
+    yv.sgd_step(pd, gr.to(DEV), md, 1e-4, first=True)
+    assert torch.equal(pd.cpu(), pe) and torch.equal(md.cpu(), me)
+    gr2 = torch.randn(n, generator=g) * 0.01
+    pe2, me2 = ot.sgd_step(pe, gr2, me, 9.75528e-5)
+    yv.sgd_step(pd, gr2.to(DEV), md, 9.75528e-5, first=False)
+    assert torch.equal(pd.cpu(), pe2) and torch.equal(md.cpu(), me2)

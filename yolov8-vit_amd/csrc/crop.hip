@@ -1,0 +1,110 @@
+// crop + nearest resize + normalize (+ patch-major layout) in one gather pass.
+//
+// Replaces, per detected object (SURVEY.md section 8 rows B1 tail, B2):
+//   PIL crop            utils/trainClass.py:92   (right/bottom exclusive)
+//   A.Resize(224,224, INTER_NEAREST) + A.Normalize(.5,.5)   utils/trainClass.py:218-221 == app.py:39-42
+//   HWC -> CHW          utils/trainClass.py:265-266
+// and additionally writes the ViT patch-embed A operand directly (layout 2), so
+// the conv k=s=P of timm's PatchEmbed becomes a plain GEMM with no im2col pass.
+//
+// HBM-bound integer/byte work: 224*224*3 source bytes gathered (crop windows are
+// small and L2-resident) and one coalesced 16-byte store per 8 output values.
+// The source-index tables follow OpenCV's rule  s = min(floor(d * (1/(dst/src))), src-1)
+// evaluated in f64 with one rounding per operation (== the host's doubles),
+// so the gather is exact by construction for any crop size.
+#include "yv_common.h"
+
+namespace {
+
+constexpr int CR_THREADS = 256;
+constexpr int CR_MAX_S = 512;
+
+__device__ __forceinline__ int nearest_src(int d, int dst, int src) {
+    double fx = __ddiv_rn((double)dst, (double)src);
+    double ifx = __ddiv_rn(1.0, fx);
+    int s = (int)floor(__dmul_rn((double)d, ifx));
+    return s < src - 1 ? s : src - 1;
+}
+
+// (x - 127.5) * fl32(1/127.5): albumentations' Normalize in f32, two roundings
+__device__ __forceinline__ float norm_u8(uint8_t v, float rcp) { return __fmul_rn(__fsub_rn((float)v, 127.5f), rcp); }
+
+// grid: (S / ROWS_PER_BLOCK, cap).  Each block produces ROWS output rows of one crop.
+template <int LAYOUT>
+__global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restrict__ images, int H, int W,
+                                                          size_t img_stride, const int32_t* __restrict__ crop_list,
+                                                          const int32_t* __restrict__ crop_total, int S, int P,
+                                                          int rows_per_block, float rcp, void* __restrict__ out) {
+    __shared__ int tx[CR_MAX_S];
+    __shared__ int ty_sh[64];
+    const int r = blockIdx.y;
+    if (crop_total && r >= crop_total[0]) return;
+    const int32_t* rec = crop_list + (size_t)r * 6;
+    const int img = rec[0], x0 = rec[1], y0 = rec[2], x1 = rec[3], y1 = rec[4];
+    const int cw = x1 - x0, ch = y1 - y0;
+    const int row0 = blockIdx.x * rows_per_block;
+    if (cw <= 0 || ch <= 0) return;      // degenerate rect: compaction never emits one; guard anyway
+    for (int d = threadIdx.x; d < S; d += CR_THREADS) tx[d] = (x0 + nearest_src(d, S, cw)) * 3;
+    for (int d = threadIdx.x; d < rows_per_block; d += CR_THREADS) ty_sh[d] = y0 + nearest_src(row0 + d, S, ch);
+    __syncthreads();
+    const uint8_t* src = images + (size_t)img * img_stride;
+    const int groups = S >> 3;                       // 8 output pixels per item
+    const int items = rows_per_block * 3 * groups;
+    for (int it = threadIdx.x; it < items; it += CR_THREADS) {
+        int g = it % groups;
+        int t = it / groups;
+        int c = t % 3;
+        int yl = t / 3;
+        int y = row0 + yl;
+        const uint8_t* line = src + (size_t)ty_sh[yl] * (size_t)W * 3 + c;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = norm_u8(line[tx[g * 8 + q]], rcp);
+        if (LAYOUT == 0) {
+            float* o = (float*)out + (((size_t)r * 3 + c) * S + y) * S + g * 8;
+            ((float4*)o)[0] = make_float4(v[0], v[1], v[2], v[3]);
+            ((float4*)o)[1] = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            uint4 pk = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                  pack_bf16x2(v[6], v[7]));
+            uint16_t* o;
+            if (LAYOUT == 1) {
+                o = (uint16_t*)out + (((size_t)r * 3 + c) * S + y) * S + g * 8;
+            } else {
+                const int gp = S / P;                // patches per side
+                const int x = g * 8;
+                const size_t row = (size_t)r * gp * gp + (size_t)(y / P) * gp + (x / P);
+                o = (uint16_t*)out + row * (size_t)(3 * P * P) + (size_t)c * P * P + (y % P) * P + (x % P);
+            }
+            *(uint4*)o = pk;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, size_t img_stride,
+                                   const int32_t* crop_list, const int32_t* crop_total, int cap, int out_size,
+                                   int patch, int layout, void* out, void* stream) {
+    if (!images || !crop_list || !out || B <= 0 || H <= 0 || W <= 0 || cap < 0) return YV_ERR_ARG;
+    if (layout < 0 || layout > 2) return YV_ERR_ARG;
+    if (out_size <= 0 || out_size > CR_MAX_S || (out_size & 7)) return YV_ERR_LIMIT;
+    if (layout == 2 && (patch < 8 || (patch & 7) || out_size % patch)) return YV_ERR_ARG;
+    if (cap == 0) return YV_OK;
+    // one block per 16 output rows (= one patch row at P=16)
+    int rows = 16;
+    if (out_size % rows) rows = 8;
+    const float rcp = 1.0f / 127.5f;                 // fl32(1/127.5), computed once on the host
+    dim3 grid(out_size / rows, cap), block(CR_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (layout == 0)
+        hipLaunchKernelGGL(crop_kernel<0>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
+                           out_size, patch, rows, rcp, out);
+    else if (layout == 1)
+        hipLaunchKernelGGL(crop_kernel<1>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
+                           out_size, patch, rows, rcp, out);
+    else
+        hipLaunchKernelGGL(crop_kernel<2>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
+                           out_size, patch, rows, rcp, out);
+    return yv_launch_status();
+}

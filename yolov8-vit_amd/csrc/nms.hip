@@ -1,0 +1,558 @@
+// NMS family for the detect -> crop hand-off.
+//
+//   yv_custom_nms        README.md:62-84          class-agnostic greedy NMS, bit-exact keep list
+//   yv_efficient_nms     tech.md:41-47            EfficientNMS_TRT output contract (KAT-2)
+//   yv_postprocess_dets  解读.md:82-99 + README.md:41 + utils/trainClass.py:70-93
+//   yv_compact_crops     device-side batch assembly (no host sync between stages)
+//
+// One workgroup owns one image / one box set: the greedy scan is sequential by
+// definition, so the parallelism is (sets) x (candidates of a set).  Scores are
+// ordered with a 64-bit key {~orderable(score), index}: every key is distinct,
+// so the order (score desc, index asc) is total and the result deterministic.
+// All IoU arithmetic is f32 with one rounding per operation (explicit _rn
+// intrinsics: no FMA contraction, IEEE divide) in torchvision's operation
+// order, which is what makes the keep list bit-exact against the reference.
+#include "yv_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t desc_key(float s) {
+    uint32_t u = __float_as_uint(s);
+    if (u == 0x80000000u) u = 0u;                                   // -0 == +0 (tie -> index order)
+    uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // order-preserving map
+    return ~asc;                                                    // smaller key = larger score
+}
+
+__device__ __forceinline__ float box_area(float4 b) { return __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y)); }
+
+__device__ __forceinline__ float iou_f32(float4 a, float area_a, float4 b, float area_b) {
+    float ltx = fmaxf(a.x, b.x), lty = fmaxf(a.y, b.y);
+    float rbx = fminf(a.z, b.z), rby = fminf(a.w, b.w);
+    float w = fmaxf(__fsub_rn(rbx, ltx), 0.0f), h = fmaxf(__fsub_rn(rby, lty), 0.0f);
+    float inter = __fmul_rn(w, h);
+    float uni = __fsub_rn(__fadd_rn(area_a, area_b), inter);
+    return __fdiv_rn(inter, uni);
+}
+
+__device__ __forceinline__ int next_pow2(int v, int lo) {
+    int p = lo;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ascending bitonic sort of np (power of two) u64 keys held in LDS
+__device__ void bitonic_sort_u64(uint64_t* k, int np) {
+    for (int size = 2; size <= np; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (np >> 1); t += blockDim.x) {
+                int lo = 2 * t - (t & (stride - 1));
+                int hi = lo + stride;
+                bool asc = ((lo & size) == 0);
+                uint64_t a = k[lo], b = k[hi];
+                if ((a > b) == asc) { k[lo] = b; k[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void alive_init(uint64_t* alive, int n, int nwords) {
+    for (int w = threadIdx.x; w < nwords; w += blockDim.x) {
+        int lo = w * 64;
+        uint64_t m = 0;
+        if (n >= lo + 64) m = ~0ull;
+        else if (n > lo) m = (~0ull) >> (64 - (n - lo));
+        alive[w] = m;
+    }
+}
+
+__device__ __forceinline__ int next_alive(const uint64_t* alive, int cur, int n, int nwords) {
+    for (int w = cur >> 6; w < nwords; ++w) {
+        uint64_t m = alive[w];
+        if (w == (cur >> 6)) m &= (~0ull) << (cur & 63);
+        if (m) {
+            int i = w * 64 + __builtin_ctzll(m);
+            return i < n ? i : n;
+        }
+    }
+    return n;
+}
+
+// greedy scan over candidates already in (score desc) order.
+//   MODE 0 (custom_nms):   a later box survives a kept box iff iou <  thr (NaN does not survive)
+//   MODE 1 (efficient):    a later box of the SAME class is dropped iff iou > thr
+// on_keep(rank, sorted_pos) is called by thread 0 for every kept box. Returns #kept (uniform).
+template <int MODE, typename OnKeep>
+__device__ int greedy_scan(const float4* sb, const int16_t* cls, int n, float thr, int max_keep, uint64_t* alive,
+                           int nwords, OnKeep on_keep) {
+    int nk = 0, cur = 0;
+    while (nk < max_keep) {
+        int i = next_alive(alive, cur, n, nwords);
+        if (i >= n) break;
+        if (threadIdx.x == 0) on_keep(nk, i);
+        ++nk;
+        float4 bi = sb[i];
+        float ai = box_area(bi);
+        int ci = MODE == 1 ? (int)cls[i] : 0;
+        for (int j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
+            if ((alive[j >> 6] >> (j & 63)) & 1ull) {
+                float4 bj = sb[j];
+                bool drop;
+                if (MODE == 0) {
+                    drop = !(iou_f32(bi, ai, bj, box_area(bj)) < thr);
+                } else {
+                    drop = ((int)cls[j] == ci) && (iou_f32(bi, ai, bj, box_area(bj)) > thr);
+                }
+                if (drop) atomicAnd((unsigned long long*)&alive[j >> 6], ~(1ull << (j & 63)));
+            }
+        }
+        __syncthreads();
+        cur = i + 1;
+    }
+    return nk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// custom_nms: one workgroup per set.  LDS: keys[np] | alive[np/64] | boxes[np] (when they fit)
+// ---------------------------------------------------------------------------------------------
+constexpr int CN_LDS_BOX_MAX = 4096;
+
+__global__ void custom_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                  const int32_t* __restrict__ counts, int n_max, int np_max, float thr,
+                                  int32_t* __restrict__ keep, int32_t* __restrict__ num_keep, float4* ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x;
+    int n = counts ? counts[s] : n_max;
+    n = n < 0 ? 0 : (n > n_max ? n_max : n);
+    uint64_t* keys = (uint64_t*)smem;
+    uint64_t* alive = keys + np_max;
+    float4* sb = (np_max <= CN_LDS_BOX_MAX) ? (float4*)(alive + (((np_max >> 6) + 2) & ~1)) : (ws + (size_t)s * n_max);
+    const float4* B = (const float4*)boxes + (size_t)s * n_max;
+    const float* S = scores + (size_t)s * n_max;
+    int32_t* K = keep + (size_t)s * n_max;
+
+    const int np = next_pow2(n, 64);
+    for (int i = threadIdx.x; i < np; i += blockDim.x)
+        keys[i] = i < n ? (((uint64_t)desc_key(S[i]) << 32) | (uint32_t)i) : ~0ull;
+    for (int i = threadIdx.x; i < n_max; i += blockDim.x) K[i] = -1;
+    bitonic_sort_u64(keys, np);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sb[i] = B[(uint32_t)keys[i]];
+    const int nwords = (np + 63) >> 6;
+    alive_init(alive, n, nwords);
+    __threadfence_block();
+    __syncthreads();
+    int nk = greedy_scan<0>(sb, nullptr, n, thr, n, alive, nwords,
+                            [&](int rank, int pos) { K[rank] = (int32_t)(uint32_t)keys[pos]; });
+    if (threadIdx.x == 0) num_keep[s] = nk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EfficientNMS contract: one workgroup (1024 threads) per image.
+// ---------------------------------------------------------------------------------------------
+constexpr int EN_MAXK = 4096;
+constexpr int EN_THREADS = 1024;
+
+struct EnShared {
+    uint32_t hist[2048];
+    uint32_t wave_cnt[16];
+    uint32_t sel_bin, sel_before, n_sel, n_eq_taken, total_cnt;
+};
+
+__device__ __forceinline__ uint32_t block_count(bool flag, uint32_t* wave_cnt) {
+    uint64_t m = __ballot(flag);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    uint32_t t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wave_cnt[w];
+    return t;
+}
+
+// exclusive rank of `flag` among the block's threads (thread order) + block total
+__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* wave_cnt, uint32_t* total) {
+    uint64_t m = __ballot(flag);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    uint32_t before = 0, t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        uint32_t c = wave_cnt[w];
+        if (w < wave) before += c;
+        t += c;
+    }
+    *total = t;
+    return before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(EN_THREADS) void efficient_nms_kernel(
+    const float* __restrict__ boxes, const float* __restrict__ scores, int A, int nc, float score_thr, float iou_thr,
+    int max_out, int pre_topk, int32_t* __restrict__ num_dets, float* __restrict__ out_boxes,
+    float* __restrict__ out_scores, int32_t* __restrict__ out_labels) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = (uint64_t*)smem;                          // EN_MAXK
+    float4* sb = (float4*)(keys + EN_MAXK);                    // EN_MAXK
+    int16_t* cls = (int16_t*)(sb + EN_MAXK);                   // EN_MAXK
+    uint64_t* alive = (uint64_t*)(cls + EN_MAXK);              // EN_MAXK/64
+    EnShared* sh = (EnShared*)(alive + EN_MAXK / 64);
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int total = A * nc;
+    const float* S = scores + (size_t)b * total;
+    const float4* Bx = (const float4*)boxes + (size_t)b * A;
+    const int chunks = (total + EN_THREADS - 1) / EN_THREADS;
+
+    for (int i = tid; i < max_out; i += EN_THREADS) {
+        ((float4*)out_boxes)[(size_t)b * max_out + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        out_scores[(size_t)b * max_out + i] = 0.f;
+        out_labels[(size_t)b * max_out + i] = 0;
+    }
+
+    // candidates above the score threshold
+    uint32_t mine = 0;
+    for (int c = 0; c < chunks; ++c) {
+        int i = c * EN_THREADS + tid;
+        if (i < total && S[i] > score_thr) ++mine;
+    }
+    if (tid == 0) sh->total_cnt = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&sh->total_cnt, mine);
+    __syncthreads();
+    const uint32_t cnt = sh->total_cnt;
+    const uint32_t K = (uint32_t)pre_topk;
+
+    // radix select of the K-th best 32-bit score key (3 digits: 11 + 11 + 10 bits)
+    uint32_t key_star = 0xFFFFFFFFu, need_eq = 0xFFFFFFFFu;      // take everything by default
+    const bool select = cnt > K;
+    if (select) {
+        uint32_t prefix = 0, need = K;
+        const int bits[3] = {11, 11, 10};
+        int consumed = 0;
+        for (int lvl = 0; lvl < 3; ++lvl) {
+            const int nb = bits[lvl], nbins = 1 << nb, shift = 32 - consumed - nb;
+            for (int i = tid; i < nbins; i += EN_THREADS) sh->hist[i] = 0;
+            __syncthreads();
+            for (int c = 0; c < chunks; ++c) {
+                int i = c * EN_THREADS + tid;
+                if (i < total) {
+                    float v = S[i];
+                    if (v > score_thr) {
+                        uint32_t k = desc_key(v);
+                        bool in_prefix = consumed == 0 ? true : ((k >> (32 - consumed)) == prefix);
+                        if (in_prefix) atomicAdd(&sh->hist[(k >> shift) & (nbins - 1)], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int per = nbins / 64, base = tid * per;
+                uint32_t local = 0;
+                for (int q = 0; q < per; ++q) local += sh->hist[base + q];
+                uint32_t incl = local;
+                for (int o = 1; o < 64; o <<= 1) {
+                    uint32_t v = __shfl_up(incl, o, 64);
+                    if (tid >= o) incl += v;
+                }
+                uint32_t excl = incl - local;
+                if (excl < need && incl >= need) {
+                    uint32_t cacc = excl;
+                    for (int q = 0; q < per; ++q) {
+                        uint32_t h = sh->hist[base + q];
+                        if (cacc + h >= need) { sh->sel_bin = base + q; sh->sel_before = cacc; break; }
+                        cacc += h;
+                    }
+                }
+            }
+            __syncthreads();
+            prefix = (prefix << nb) | sh->sel_bin;
+            need -= sh->sel_before;
+            consumed += nb;
+            __syncthreads();
+        }
+        key_star = prefix;
+        need_eq = need;              // how many of the candidates with key == key_star to take (index order)
+    }
+
+    // compaction of the selected set into LDS keys (set is exact; order fixed by the sort below)
+    if (tid == 0) { sh->n_sel = 0; sh->n_eq_taken = 0; }
+    __syncthreads();
+    for (int c = 0; c < chunks; ++c) {
+        int i = c * EN_THREADS + tid;
+        bool pass = false, eq = false;
+        uint32_t k = 0;
+        if (i < total) {
+            float v = S[i];
+            if (v > score_thr) {
+                k = desc_key(v);
+                pass = !select || k < key_star;
+                eq = select && k == key_star;
+            }
+        }
+        bool take = pass;
+        if (select) {                                           // ties on the cut score: lowest flat index first
+            uint32_t tot;
+            uint32_t r = block_rank(eq, sh->wave_cnt, &tot);
+            uint32_t base = sh->n_eq_taken;
+            if (eq && base + r < need_eq) take = true;
+            __syncthreads();
+            if (tid == 0) sh->n_eq_taken = base + tot;
+        }
+        if (take) {
+            uint32_t pos = atomicAdd(&sh->n_sel, 1u);
+            if (pos < (uint32_t)EN_MAXK) keys[pos] = ((uint64_t)k << 32) | (uint32_t)i;
+        }
+        if (select) __syncthreads();
+    }
+    __syncthreads();
+    int n = (int)min(sh->n_sel, (uint32_t)EN_MAXK);
+    const int np = next_pow2(n, 64);
+    for (int i = n + tid; i < np; i += EN_THREADS) keys[i] = ~0ull;
+    bitonic_sort_u64(keys, np);
+    for (int i = tid; i < n; i += EN_THREADS) {
+        uint32_t flat = (uint32_t)keys[i];
+        sb[i] = Bx[flat / (uint32_t)nc];
+        cls[i] = (int16_t)(flat % (uint32_t)nc);
+    }
+    const int nwords = (np + 63) >> 6;
+    alive_init(alive, n, nwords);
+    __syncthreads();
+    int nk = greedy_scan<1>(sb, cls, n, iou_thr, max_out, alive, nwords, [&](int rank, int pos) {
+        uint32_t flat = (uint32_t)keys[pos];
+        ((float4*)out_boxes)[(size_t)b * max_out + rank] = sb[pos];
+        out_scores[(size_t)b * max_out + rank] = S[flat];
+        out_labels[(size_t)b * max_out + rank] = (int32_t)cls[pos];
+    });
+    if (tid == 0) num_dets[b] = nk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// postprocess: restore coords, score filter, dedupe (custom_nms), int cast, inflate.
+// ---------------------------------------------------------------------------------------------
+constexpr int PP_MAX_SLOTS = 1024;
+constexpr int PP_THREADS = 128;
+
+__device__ __forceinline__ int floordiv_pos(int a, int b) {      // Python a // b for b > 0
+    int q = a / b;
+    if ((a % b != 0) && (a < 0)) --q;
+    return q;
+}
+__device__ __forceinline__ int f2i(float v, int mode) {
+    if (!(v == v)) return 0;
+    v = fminf(fmaxf(v, -1.0e9f), 1.0e9f);
+    if (mode == 1) v = rintf(v);                                 // half to even, like torch.round
+    return (int)v;                                               // toward zero, like Python int()
+}
+
+__global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
+    const int32_t* __restrict__ num_dets, const float* __restrict__ bboxes, const float* __restrict__ scores,
+    const int32_t* __restrict__ labels, int slots, int np, const float* __restrict__ ratio,
+    const float* __restrict__ dwdh, const int32_t* __restrict__ img_wh, float conf, float dedupe_iou, int coord_mode,
+    int max_crops, int32_t* __restrict__ det_count, int32_t* __restrict__ det_box, float* __restrict__ det_score,
+    int32_t* __restrict__ det_label, int32_t* __restrict__ crop_rect, int32_t* __restrict__ crop_ok) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = (uint64_t*)smem;                 // np
+    float4* sb = (float4*)(keys + np);                // np
+    uint64_t* alive = (uint64_t*)(sb + np);           // np/64 + 1
+    int32_t* kept_pos = (int32_t*)(alive + (np >> 6) + 1);   // np
+    int& n_pass_sh = *(int*)(kept_pos + np);                 // all LDS in the dynamic region (16-B aligned base)
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int n = num_dets[b];
+    n = n < 0 ? 0 : (n > slots ? slots : n);
+    const float r = ratio[b], dw = dwdh[2 * b], dh = dwdh[2 * b + 1];
+    const float4* Bx = (const float4*)bboxes + (size_t)b * slots;
+    const float* S = scores + (size_t)b * slots;
+
+    if (tid == 0) n_pass_sh = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int j = tid; j < np; j += PP_THREADS) {
+        uint64_t k = ~0ull;
+        if (j < n) {
+            float sc = S[j];
+            if (!(sc < conf)) {                       // `if score < 0.35: continue`
+                k = ((uint64_t)desc_key(sc) << 32) | (uint32_t)j;
+                ++mine;
+            }
+        }
+        keys[j] = k;
+    }
+    if (mine) atomicAdd(&n_pass_sh, mine);
+    for (int j = tid; j < slots; j += PP_THREADS) {
+        size_t o = (size_t)b * slots + j;
+        ((int4*)det_box)[o] = make_int4(0, 0, 0, 0);
+        ((int4*)crop_rect)[o] = make_int4(0, 0, 0, 0);
+        det_score[o] = 0.f;
+        det_label[o] = 0;
+        crop_ok[o] = 0;
+    }
+    bitonic_sort_u64(keys, np);
+    const int m = n_pass_sh;
+    for (int i = tid; i < m; i += PP_THREADS) {
+        float4 v = Bx[(uint32_t)keys[i]];
+        // bboxes -= dwdh ; bboxes /= ratio   (f32, two roundings per coordinate)
+        v.x = __fdiv_rn(__fsub_rn(v.x, dw), r);
+        v.y = __fdiv_rn(__fsub_rn(v.y, dh), r);
+        v.z = __fdiv_rn(__fsub_rn(v.z, dw), r);
+        v.w = __fdiv_rn(__fsub_rn(v.w, dh), r);
+        sb[i] = v;
+    }
+    const int nwords = (np + 63) >> 6;
+    alive_init(alive, m, nwords);
+    __syncthreads();
+    const int cap = max_crops > 0 ? (max_crops < m ? max_crops : m) : m;
+    int nk;
+    if (dedupe_iou > 0.0f) {
+        nk = greedy_scan<0>(sb, nullptr, m, dedupe_iou, cap, alive, nwords,
+                            [&](int rank, int pos) { kept_pos[rank] = pos; });
+    } else {                                         // dedupe disabled: every filtered detection is reported
+        nk = cap;
+        for (int i = tid; i < nk; i += PP_THREADS) kept_pos[i] = i;
+    }
+    __syncthreads();
+    const int W = img_wh[2 * b], H = img_wh[2 * b + 1];
+    for (int k = tid; k < nk; k += PP_THREADS) {
+        const int pos = kept_pos[k];
+        const uint32_t slot = (uint32_t)keys[pos];
+        const float4 v = sb[pos];
+        int x_min = f2i(v.x, coord_mode), y_min = f2i(v.y, coord_mode);
+        int x_max = f2i(v.z, coord_mode), y_max = f2i(v.w, coord_mode);
+        size_t o = (size_t)b * slots + k;
+        ((int4*)det_box)[o] = make_int4(x_min, y_min, x_max, y_max);
+        det_score[o] = S[slot];
+        det_label[o] = labels[(size_t)b * slots + slot];
+        // crop_image, eval branch (utils/trainClass.py:76-77,85-91)
+        int dis_x = floordiv_pos(x_max - x_min, 10), dis_y = floordiv_pos(y_max - y_min, 10);
+        int hx = floordiv_pos(dis_x, 2), hy = floordiv_pos(dis_y, 2);
+        int cx1 = min(W, x_max + hx), cx0 = max(0, x_min - hx);
+        int cy1 = min(H, y_max + hy), cy0 = max(0, y_min - hy);
+        ((int4*)crop_rect)[o] = make_int4(cx0, cy0, cx1, cy1);
+        crop_ok[o] = (cx1 > cx0 && cy1 > cy0) ? 1 : 0;
+    }
+    if (tid == 0) det_count[b] = nk;
+}
+
+__global__ void compact_crops_kernel(const int32_t* __restrict__ det_count, const int32_t* __restrict__ crop_rect,
+                                     const int32_t* __restrict__ crop_ok, int B, int slots, int cap,
+                                     int32_t* __restrict__ crop_list, int32_t* __restrict__ crop_total) {
+    // single workgroup: images are few (<= a few thousand); order = image, then detection rank
+    __shared__ int32_t base_sh;
+    __shared__ uint32_t wave_cnt[16];
+    const int tid = threadIdx.x;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    const int total_items = B * slots;
+    for (int c0 = 0; c0 < total_items; c0 += blockDim.x) {
+        int i = c0 + tid;
+        bool ok = false;
+        int b = 0, k = 0;
+        if (i < total_items) {
+            b = i / slots;
+            k = i - b * slots;
+            ok = k < det_count[b] && crop_ok[i] != 0;
+        }
+        uint32_t tot;
+        uint32_t rnk = block_rank(ok, wave_cnt, &tot);
+        int base = base_sh;
+        if (ok) {
+            int pos = base + (int)rnk;
+            if (pos < cap) {
+                int4 rc = ((const int4*)crop_rect)[i];
+                int32_t* o = crop_list + (size_t)pos * 6;
+                o[0] = b; o[1] = rc.x; o[2] = rc.y; o[3] = rc.z; o[4] = rc.w; o[5] = k;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) base_sh = base + (int)tot;
+        __syncthreads();
+    }
+    int total = base_sh < cap ? base_sh : cap;
+    for (int p = total + tid; p < cap; p += blockDim.x) {
+        int32_t* o = crop_list + (size_t)p * 6;
+        o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0;
+    }
+    if (tid == 0) crop_total[0] = total;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- C ABI
+extern "C" size_t yv_custom_nms_ws_bytes(int n_sets, int n_max) {
+    if (n_sets <= 0 || n_max <= 0) return 0;
+    int np = 64;
+    while (np < n_max) np <<= 1;
+    return np <= CN_LDS_BOX_MAX ? 0 : (size_t)n_sets * (size_t)n_max * sizeof(float4);
+}
+
+extern "C" int yv_custom_nms(const float* boxes, const float* scores, const int32_t* counts, int n_sets, int n_max,
+                             float iou_threshold, int32_t* keep, int32_t* num_keep, void* ws, size_t ws_bytes,
+                             void* stream) {
+    if (n_sets < 0 || n_max < 0 || !keep || !num_keep) return YV_ERR_ARG;
+    if (n_sets == 0) return YV_OK;
+    if (n_max == 0) {
+        hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int32_t) * (size_t)n_sets, (hipStream_t)stream);
+        return e == hipSuccess ? YV_OK : YV_ERR_LAUNCH;
+    }
+    if (!boxes || !scores) return YV_ERR_ARG;
+    if (n_max > 16384) return YV_ERR_LIMIT;
+    int np = 64;
+    while (np < n_max) np <<= 1;
+    size_t need = yv_custom_nms_ws_bytes(n_sets, n_max);
+    if (need && (!ws || ws_bytes < need)) return YV_ERR_WORKSPACE;
+    size_t lds = (size_t)np * 8 + (size_t)(((np >> 6) + 2) & ~1) * 8 + (np <= CN_LDS_BOX_MAX ? (size_t)np * 16 : 0);
+    int threads = np < 1024 ? np : 1024;
+    if (hipFuncSetAttribute((const void*)custom_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+        return YV_ERR_LAUNCH;
+    hipLaunchKernelGGL(custom_nms_kernel, dim3(n_sets), dim3(threads), lds, (hipStream_t)stream, boxes, scores, counts,
+                       n_max, np, iou_threshold, keep, num_keep, (float4*)ws);
+    return yv_launch_status();
+}
+
+extern "C" int yv_efficient_nms(const float* boxes, const float* scores, int B, int A, int nc, float score_threshold,
+                                float iou_threshold, int max_out, int pre_topk, int32_t* num_dets, float* out_boxes,
+                                float* out_scores, int32_t* out_labels, void* stream) {
+    if (B < 0 || A <= 0 || nc <= 0 || max_out <= 0 || !boxes || !scores || !num_dets || !out_boxes || !out_scores ||
+        !out_labels)
+        return YV_ERR_ARG;
+    if (B == 0) return YV_OK;
+    if (pre_topk <= 0 || pre_topk > EN_MAXK || nc > 32767 || (long long)A * nc > 0x7fffffffLL) return YV_ERR_LIMIT;
+    size_t lds = (size_t)EN_MAXK * (8 + 16 + 2) + (EN_MAXK / 64) * 8 + sizeof(EnShared) + 16;
+    if (hipFuncSetAttribute((const void*)efficient_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return YV_ERR_LAUNCH;
+    hipLaunchKernelGGL(efficient_nms_kernel, dim3(B), dim3(EN_THREADS), lds, (hipStream_t)stream, boxes, scores, A, nc,
+                       score_threshold, iou_threshold, max_out, pre_topk, num_dets, out_boxes, out_scores, out_labels);
+    return yv_launch_status();
+}
+
+extern "C" int yv_postprocess_dets(const int32_t* num_dets, const float* bboxes, const float* scores,
+                                   const int32_t* labels, int B, int slots, const float* ratio, const float* dwdh,
+                                   const int32_t* img_wh, float conf_threshold, float dedupe_iou, int coord_mode,
+                                   int max_crops, int32_t* det_count, int32_t* det_box, float* det_score,
+                                   int32_t* det_label, int32_t* crop_rect, int32_t* crop_ok, void* stream) {
+    if (B < 0 || slots <= 0 || !num_dets || !bboxes || !scores || !labels || !ratio || !dwdh || !img_wh ||
+        !det_count || !det_box || !det_score || !det_label || !crop_rect || !crop_ok)
+        return YV_ERR_ARG;
+    if (coord_mode != 0 && coord_mode != 1) return YV_ERR_ARG;
+    if (B == 0) return YV_OK;
+    if (slots > PP_MAX_SLOTS) return YV_ERR_LIMIT;
+    int np = 64;
+    while (np < slots) np <<= 1;
+    size_t lds = (size_t)np * (8 + 16 + 4) + ((size_t)(np >> 6) + 1) * 8 + 16;
+    hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(PP_THREADS), lds, (hipStream_t)stream, num_dets, bboxes,
+                       scores, labels, slots, np, ratio, dwdh, img_wh, conf_threshold, dedupe_iou, coord_mode,
+                       max_crops, det_count, det_box, det_score, det_label, crop_rect, crop_ok);
+    return yv_launch_status();
+}
+
+extern "C" int yv_compact_crops(const int32_t* det_count, const int32_t* crop_rect, const int32_t* crop_ok, int B,
+                                int slots, int cap, int32_t* crop_list, int32_t* crop_total, void* stream) {
+    if (B < 0 || slots <= 0 || cap < 0 || !det_count || !crop_rect || !crop_ok || !crop_list || !crop_total)
+        return YV_ERR_ARG;
+    hipLaunchKernelGGL(compact_crops_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, det_count, crop_rect,
+                       crop_ok, B, slots, cap, crop_list, crop_total);
+    return yv_launch_status();
+}

@@ -1,0 +1,99 @@
+// Fine-tune scalar-side kernels.
+//   yv_loss_fwd_bwd  build_loss = LSCE(0.1)/6 + Focal(alpha 1, gamma 2, mean)*5/6
+//                    utils/trainClass.py:46-66,162-185,362-370  (forward value + d/dlogits)
+//   yv_sgd_step      torch.optim.SGD(lr, momentum=0.9, weight_decay=1e-3)   utils/trainClass.py:442-443
+// The loss is (B,5): latency-bound, one workgroup.  SGD is a 20 B/param HBM stream
+// (read p,g,m; write p,m) issued as 16-byte accesses.
+#include "yv_common.h"
+
+namespace {
+
+constexpr int LOSS_MAX_NC = 32;
+
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                   int B, int nc, float* __restrict__ loss, float* __restrict__ grad) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const float inv_b = 1.0f / (float)B, inv_bc = 1.0f / ((float)B * (float)nc), inv_c = 1.0f / (float)nc;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float* x = logits + (size_t)i * nc;
+        const int y = labels[i];
+        float m = x[0];
+        for (int c = 1; c < nc; ++c) m = fmaxf(m, x[c]);
+        float e[LOSS_MAX_NC], den = 0.f;
+        for (int c = 0; c < nc; ++c) { e[c] = expf(x[c] - m); den += e[c]; }
+        float cross = 0.f, smooth = 0.f, fl = 0.f;
+        for (int c = 0; c < nc; ++c) {
+            const float p = e[c] / den;                       // y_hat = softmax(x)
+            const float nl = -logf(p);                        // -log(y_hat)
+            smooth += nl;
+            if (c == y) cross = nl;
+            const float t = c == y ? 1.f : 0.f;
+            const float xc = x[c];
+            const float bce = fmaxf(xc, 0.f) - xc * t + log1pf(expf(-fabsf(xc)));
+            const float pt = expf(-bce);
+            const float om = 1.f - pt;
+            fl += om * om * bce;
+            const float sig = 1.f / (1.f + expf(-xc));
+            const float g_ls = (p - 0.9f * t - 0.1f * inv_c) * inv_b;
+            const float g_fo = (sig - t) * om * (2.f * pt * bce + om) * inv_bc;
+            grad[(size_t)i * nc + c] = g_ls * (1.f / 6.f) + g_fo * (5.f / 6.f);
+        }
+        acc += (0.9f * cross + 0.1f * smooth * inv_c) * inv_b * (1.f / 6.f) + fl * inv_bc * (5.f / 6.f);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ m, size_t n, float lr, float mu, float wd,
+                                                  int first) {
+    const size_t n4 = n >> 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = ((float4*)p)[i], gv = ((const float4*)g)[i], mv;
+        float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x, gv.y, gv.z, gv.w}, me[4];
+        if (!first) { mv = ((float4*)m)[i]; me[0] = mv.x; me[1] = mv.y; me[2] = mv.z; me[3] = mv.w; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float gq = __fadd_rn(ge[q], __fmul_rn(wd, pe[q]));
+            me[q] = first ? gq : __fadd_rn(__fmul_rn(mu, me[q]), gq);
+            pe[q] = __fsub_rn(pe[q], __fmul_rn(lr, me[q]));
+        }
+        ((float4*)p)[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+        ((float4*)m)[i] = make_float4(me[0], me[1], me[2], me[3]);
+    }
+    // tail (< 4 elements)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        size_t i = (n4 << 2) + threadIdx.x;
+        float gq = __fadd_rn(g[i], __fmul_rn(wd, p[i]));
+        float mq = first ? gq : __fadd_rn(__fmul_rn(mu, m[i]), gq);
+        m[i] = mq;
+        p[i] = __fsub_rn(p[i], __fmul_rn(lr, mq));
+    }
+}
+
+}  // namespace
+
+extern "C" int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, float* loss, float* grad,
+                               void* stream) {
+    if (!logits || !labels || !loss || !grad || B <= 0 || nc <= 0) return YV_ERR_ARG;
+    if (nc > LOSS_MAX_NC) return YV_ERR_LIMIT;
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, B, nc, loss, grad);
+    return yv_launch_status();
+}
+
+extern "C" int yv_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum,
+                           float weight_decay, int first, void* stream) {
+    if (!p || !g || !m) return YV_ERR_ARG;
+    if (n == 0) return YV_OK;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m) & 15) return YV_ERR_ARG;
+    size_t n4 = n >> 2;
+    size_t want = (n4 + 255) / 256;
+    int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, n, lr, momentum,
+                       weight_decay, first);
+    return yv_launch_status();
+}

@@ -1,0 +1,244 @@
+"""ctypes binding of libyvhip.so (include/yv_hip.h) + thin tensor-level wrappers.
+
+PyTorch-ROCm is used only as plumbing: device memory (`tensor.data_ptr()`),
+the current HIP stream and `torch.distributed`.  Every op below enqueues
+hand-written gfx950 kernels through the C ABI; there is NO fallback path: if the
+library is missing or a call fails, a `YvError` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import List, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyvhip.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "yv_hip.h"))
+
+
+class YvError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise YvError(f"{LIB_PATH} is missing: build it with `make -C yolov8-vit_amd/csrc` "
+                      "(or __graft_entry__.build()); there is no CPU fallback")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class yv_view(C.Structure):
+    _fields_ = [("ptr", _vp), ("ld", _i), ("c", _i), ("up", _i)]
+
+
+_SIGS = {
+    "yv_version": (_i, []),
+    "yv_error_string": (C.c_char_p, [_i]),
+    "yv_device_is_gfx950": (_i, []),
+    "yv_custom_nms_ws_bytes": (_sz, [_i, _i]),
+    "yv_custom_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "yv_efficient_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "yv_postprocess_dets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _i, _i,
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "yv_compact_crops": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "yv_crop_resize_norm": (_i, [_vp, _i, _i, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "yv_conv2d": (_i, [C.POINTER(yv_view), C.POINTER(yv_view), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
+                       _i, _vp]),
+    "yv_linear": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "yv_layernorm": (_i, [_vp, _sz, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _vp]),
+    "yv_attention": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "yv_cls_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "yv_wrapper_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "yv_sppf_pool": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "yv_stem_conv": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "yv_loss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "yv_sgd_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _vp]),
+}
+
+
+def header_symbols() -> List[str]:
+    """Every function include/yv_hip.h declares (used by the CPU symbol test)."""
+    txt = open(HEADER_PATH, encoding="utf-8").read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(yv_[a-z0-9_]+)\s*\(", txt)))
+
+
+MISSING: List[str] = []
+
+
+def _bind():
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:           # header/library mismatch: recorded, and calling it raises
+            MISSING.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+
+
+_bind()
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        raise YvError(f"{what or 'libyvhip'}: {lib.yv_error_string(code).decode()} ({code})")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise YvError("no HIP device visible: the hot path has no CPU fallback")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise YvError("expected a device tensor")
+            if not t.is_contiguous():
+                raise YvError("expected a contiguous tensor")
+
+
+# ------------------------------------------------------------------ boxes
+def custom_nms_batched(boxes: torch.Tensor, scores: torch.Tensor, counts: Optional[torch.Tensor],
+                       iou_threshold: float = 0.45):
+    """boxes (S,n,4) f32, scores (S,n) f32, counts (S) i32|None -> keep (S,n) i32 (-1 padded), num (S) i32."""
+    _chk_dev(boxes, scores, counts)
+    S, n = scores.shape
+    keep = torch.empty((S, n), dtype=torch.int32, device=boxes.device)
+    num = torch.empty((S,), dtype=torch.int32, device=boxes.device)
+    wsb = lib.yv_custom_nms_ws_bytes(S, n)
+    ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=boxes.device)
+    check(lib.yv_custom_nms(_p(boxes), _p(scores), _p(counts), S, n, float(iou_threshold), _p(keep), _p(num),
+                            _p(ws), wsb, _st()), "yv_custom_nms")
+    return keep, num
+
+
+def custom_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float = 0.45) -> List[int]:
+    """Reference signature (README.md:62): returns a Python list of kept ORIGINAL indices."""
+    require_gpu()
+    n = int(scores.shape[0])
+    if n == 0:
+        return []
+    dev = torch.device("cuda", torch.cuda.current_device())
+    b = boxes.to(device=dev, dtype=torch.float32).reshape(1, n, 4).contiguous()
+    s = scores.to(device=dev, dtype=torch.float32).reshape(1, n).contiguous()
+    keep, num = custom_nms_batched(b, s, None, iou_threshold)
+    k = int(num[0])
+    return keep[0, :k].tolist()
+
+
+def efficient_nms(boxes: torch.Tensor, scores: torch.Tensor, score_threshold: float = 0.25,
+                  iou_threshold: float = 0.65, max_output_boxes: int = 100, pre_nms_topk: int = 4096):
+    """boxes (B,A,4), scores (B,A,nc) f32 -> (num_dets (B,1) i32, bboxes (B,K,4), scores (B,K), labels (B,K) i32)."""
+    _chk_dev(boxes, scores)
+    B, A, nc = scores.shape
+    K = max_output_boxes
+    dev = boxes.device
+    num = torch.empty((B, 1), dtype=torch.int32, device=dev)
+    ob = torch.empty((B, K, 4), dtype=torch.float32, device=dev)
+    osc = torch.empty((B, K), dtype=torch.float32, device=dev)
+    ol = torch.empty((B, K), dtype=torch.int32, device=dev)
+    check(lib.yv_efficient_nms(_p(boxes), _p(scores), B, A, nc, float(score_threshold), float(iou_threshold), K,
+                               int(pre_nms_topk), _p(num), _p(ob), _p(osc), _p(ol), _st()), "yv_efficient_nms")
+    return num, ob, osc, ol
+
+
+def postprocess_dets(num_dets, bboxes, scores, labels, ratio, dwdh, img_wh, conf=0.35, dedupe_iou=0.45,
+                     coord_mode: str = "trunc", max_crops: int = 0):
+    _chk_dev(num_dets, bboxes, scores, labels, ratio, dwdh, img_wh)
+    B, slots = scores.shape
+    dev = scores.device
+    out = {
+        "det_count": torch.empty((B,), dtype=torch.int32, device=dev),
+        "det_box": torch.empty((B, slots, 4), dtype=torch.int32, device=dev),
+        "det_score": torch.empty((B, slots), dtype=torch.float32, device=dev),
+        "det_label": torch.empty((B, slots), dtype=torch.int32, device=dev),
+        "crop_rect": torch.empty((B, slots, 4), dtype=torch.int32, device=dev),
+        "crop_ok": torch.empty((B, slots), dtype=torch.int32, device=dev),
+    }
+    check(lib.yv_postprocess_dets(_p(num_dets), _p(bboxes), _p(scores), _p(labels), B, slots, _p(ratio), _p(dwdh),
+                                  _p(img_wh), float(conf), float(dedupe_iou), 1 if coord_mode == "round" else 0,
+                                  int(max_crops), _p(out["det_count"]), _p(out["det_box"]), _p(out["det_score"]),
+                                  _p(out["det_label"]), _p(out["crop_rect"]), _p(out["crop_ok"]), _st()),
+          "yv_postprocess_dets")
+    return out
+
+
+def compact_crops(det_count, crop_rect, crop_ok, cap: int):
+    _chk_dev(det_count, crop_rect, crop_ok)
+    B, slots = crop_ok.shape
+    dev = crop_ok.device
+    crop_list = torch.empty((max(cap, 1), 6), dtype=torch.int32, device=dev)
+    total = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(lib.yv_compact_crops(_p(det_count), _p(crop_rect), _p(crop_ok), B, slots, cap, _p(crop_list), _p(total),
+                               _st()), "yv_compact_crops")
+    return crop_list, total
+
+
+def crop_resize_norm(images: torch.Tensor, crop_list: torch.Tensor, crop_total: Optional[torch.Tensor], cap: int,
+                     out_size: int = 224, patch: int = 16, layout: int = 2, out: Optional[torch.Tensor] = None):
+    """images (B,H,W,3) u8 -> layout 0: (cap,3,S,S) f32 | 1: same bf16 | 2: (cap*(S/P)^2, 3*P*P) bf16."""
+    _chk_dev(images, crop_list, crop_total)
+    B, H, W, _ = images.shape
+    dev = images.device
+    if out is None:
+        if layout == 0:
+            out = torch.zeros((cap, 3, out_size, out_size), dtype=torch.float32, device=dev)
+        elif layout == 1:
+            out = torch.zeros((cap, 3, out_size, out_size), dtype=torch.bfloat16, device=dev)
+        else:
+            g = out_size // patch
+            out = torch.zeros((cap * g * g, 3 * patch * patch), dtype=torch.bfloat16, device=dev)
+    check(lib.yv_crop_resize_norm(_p(images), B, H, W, H * W * 3, _p(crop_list), _p(crop_total), cap, out_size,
+                                  patch, layout, _p(out), _st()), "yv_crop_resize_norm")
+    return out
+
+
+def detect_decode(box_logits, cls_logits, size: int, nc: int):
+    """box_logits: 3 x (B,Hs,Ws,64) f32; cls_logits: 3 x (B,Hs,Ws,ld) f32 -> boxes (B,A,4), scores (B,A,nc)."""
+    _chk_dev(*box_logits, *cls_logits)
+    B = box_logits[0].shape[0]
+    ld = cls_logits[0].shape[-1]
+    A = sum((size // s) ** 2 for s in (8, 16, 32))
+    dev = box_logits[0].device
+    boxes = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, A, nc), dtype=torch.float32, device=dev)
+    check(lib.yv_detect_decode(_p(box_logits[0]), _p(box_logits[1]), _p(box_logits[2]), _p(cls_logits[0]),
+                               _p(cls_logits[1]), _p(cls_logits[2]), ld, B, size, nc, _p(boxes), _p(scores), _st()),
+          "yv_detect_decode")
+    return boxes, scores
+
+
+# --------------------------------------------------------------- training
+def loss_fwd_bwd(logits: torch.Tensor, labels: torch.Tensor):
+    _chk_dev(logits, labels)
+    B, nc = logits.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits)
+    check(lib.yv_loss_fwd_bwd(_p(logits), _p(labels), B, nc, _p(loss), _p(grad), _st()), "yv_loss_fwd_bwd")
+    return loss, grad
+
+
+def sgd_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, momentum: float = 0.9,
+             weight_decay: float = 1e-3, first: bool = False):
+    _chk_dev(p, g, m)
+    check(lib.yv_sgd_step(_p(p), _p(g), _p(m), p.numel(), float(lr), float(momentum), float(weight_decay),
+                          1 if first else 0, _st()), "yv_sgd_step")
