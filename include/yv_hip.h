@@ -135,15 +135,17 @@ int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout,
 /* Linear: out[M,N] = A[M,K] @ W[N,K]^T (+bias)(+GELU)(+residual) on MFMA
  * (timm Attention.qkv/proj, Mlp.fc1/fc2, head; README.md:21-35).
  * A (M,K) bf16 row stride lda; W (N,K) bf16; bias (N) f32.
- * m_dev: optional device i32 overriding M at run time (tiles beyond it exit).
+ * m_dev: optional device i32; rows at run time = min(M, m_dev[0]*m_mul) (tiles beyond exit):
+ *        the crop count of a batch is only known on the device (no host sync).
  * YV_EPI_POSEMB: row m -> out row (m/tok)*(tok+1)+1+(m%tok), adds pos[(1+m%tok)*N + n]. */
 int yv_linear(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out, int ldo,
-              const float* pos, int tok, int flags, const int32_t* m_dev, void* stream);
+              const float* pos, int tok, int flags, const int32_t* m_dev, int m_mul, void* stream);
 
 /* LayerNorm over the last dim (timm blocks.*.norm1/2, norm; eps 1e-6; README.md:21-29).
- * x (rows, D) f32 with row stride ldx -> y (rows, D) bf16 row stride ldy. */
+ * x (rows, D) f32 with row stride ldx -> y (rows, D) bf16 row stride ldy.
+ * count_dev: optional device i32; rows at run time = min(rows, count_dev[0]*rows_per_count). */
 int yv_layernorm(const float* x, size_t ldx, const float* gamma, const float* beta, int rows, int D, float eps,
-                 void* y, size_t ldy, const int32_t* rows_dev, void* stream);
+                 void* y, size_t ldy, const int32_t* count_dev, int rows_per_count, void* stream);
 
 /* Fused attention forward, non-causal: softmax(Q K^T * scale) V (timm Attention; README.md:21-23).
  * qkv (R*N, 3*H*64) bf16 as produced by the qkv Linear ([q|k|v], head-major);

@@ -1,0 +1,219 @@
+"""GPU parity of the dense kernels (MFMA GEMM / implicit-GEMM conv / attention / LayerNorm /
+head / pool / stem) against plain PyTorch fp32 on the CPU.  Inputs are bf16-representable so
+the only differences are accumulation order and the bf16 rounding of the OUTPUT:
+tolerances are written per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def yv():
+    import yvhip
+    yvhip.require_gpu()
+    return yvhip
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 768, 768), (197 * 3, 2304, 768), (130, 1000 + 24, 768),
+                                   (64, 16, 144), (257, 40, 72), (1000, 64, 576)])
+def test_linear_plain(yv, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    ref = a.float() @ w.float().t() + bias
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    yv.linear(a.to(DEV), w.to(DEV), bias.to(DEV), out, flags=yv.EPI_OUT_F32)
+    # f32 accumulate of exact bf16 products: only summation order differs
+    assert torch.allclose(out.cpu(), ref, atol=1e-3, rtol=1e-4)
+    outb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    yv.linear(a.to(DEV), w.to(DEV), bias.to(DEV), outb)
+    assert rel_l2(outb.cpu().float(), ref) < 3e-3                 # bf16 output rounding (2^-9)
+
+
+def test_linear_epilogues(yv):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 394, 256, 128
+    a = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g)
+    lin = a.float() @ w.float().t() + bias
+    # exact-erf GELU -> bf16
+    o = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    yv.linear(a.to(DEV), w.to(DEV), bias.to(DEV), o, flags=yv.EPI_GELU)
+    assert rel_l2(o.cpu().float(), F.gelu(lin)) < 4e-3
+    # f32 residual stream read-modify-write
+    x = torch.randn(M, N, generator=g)
+    xd = x.to(DEV)
+    yv.linear(a.to(DEV), w.to(DEV), bias.to(DEV), xd, flags=yv.EPI_RES_F32)
+    assert torch.allclose(xd.cpu(), x + lin, atol=1e-3, rtol=1e-4)
+    # patch-embed row remap + pos_embed (tok = 197-1 -> small: tok = 2)
+    tok = 2
+    pos = torch.randn(tok + 1, N, generator=g)
+    R = M // tok
+    xo = torch.full((R * (tok + 1), N), 7.0, device=DEV)
+    yv.linear(a.to(DEV), w.to(DEV), bias.to(DEV), xo, flags=yv.EPI_OUT_F32 | yv.EPI_POSEMB, pos=pos.to(DEV), tok=tok)
+    exp = torch.full((R, tok + 1, N), 7.0)
+    exp[:, 1:] = lin.view(R, tok, N) + pos[1:]
+    assert torch.allclose(xo.cpu().view(R, tok + 1, N), exp, atol=1e-3, rtol=1e-4)
+    # device-side dynamic M
+    md = torch.tensor([3], dtype=torch.int32, device=DEV)
+    o2 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    yv.linear(a.to(DEV), w.to(DEV), bias.to(DEV), o2, flags=yv.EPI_OUT_F32, m_dev=md, m_mul=50)
+    assert torch.allclose(o2.cpu()[:150], lin[:150], atol=1e-3, rtol=1e-4) and float(o2[150:].abs().sum()) == 0
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k,s", [(2, 16, 32, 40, 3, 2), (1, 32, 32, 24, 3, 1), (2, 64, 128, 20, 3, 2),
+                                               (3, 48, 32, 16, 1, 1), (1, 256, 256, 20, 1, 1), (2, 64, 64, 20, 3, 1),
+                                               (1, 128, 16, 12, 3, 1), (2, 24, 8, 10, 3, 1)])
+def test_conv_vs_torch(yv, B, Cin, Cout, H, k, s):
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H + k)
+    x = bf(torch.randn(B, Cin, H, H, generator=g))
+    w = bf(torch.randn(Cout, Cin, k, k, generator=g) * math.sqrt(2.0 / (Cin * k * k)))
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x.float(), w.float(), b, stride=s, padding=k // 2))
+    Ho = ref.shape[-1]
+    xin = _nhwc(x).to(DEV)
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(DEV)
+    out = torch.zeros(B, Ho, Ho, Cout + 8, dtype=torch.bfloat16, device=DEV)
+    yv.conv2d(yv.view(xin, 0, Cin), None, B, Ho, Ho, k, s, wk, b.to(DEV), out, 8, yv.EPI_SILU)
+    got = out[..., 8:].permute(0, 3, 1, 2).float().cpu()
+    assert rel_l2(got, ref) < 4e-3
+    assert float(out[..., :8].abs().sum()) == 0                     # channel offset respected
+    # f32 output without activation (detect head tail)
+    out32 = torch.zeros(B, Ho, Ho, Cout, dtype=torch.float32, device=DEV)
+    yv.conv2d(yv.view(xin, 0, Cin), None, B, Ho, Ho, k, s, wk, b.to(DEV), out32, 0, yv.EPI_OUT_F32)
+    ref2 = F.conv2d(x.float(), w.float(), b, stride=s, padding=k // 2)
+    assert torch.allclose(out32.permute(0, 3, 1, 2).cpu(), ref2, atol=2e-3, rtol=1e-4)
+
+
+def test_conv_concat_upsample_residual(yv):
+    g = torch.Generator().manual_seed(9)
+    B, H = 2, 20
+    small = bf(torch.randn(B, 32, H // 2, H // 2, generator=g)); skip = bf(torch.randn(B, 16, H, H, generator=g))
+    w = bf(torch.randn(24, 48, 1, 1, generator=g) * 0.2); b = torch.randn(24, generator=g) * 0.1
+    cat = torch.cat([F.interpolate(small.float(), scale_factor=2, mode="nearest"), skip.float()], 1)
+    ref = F.silu(F.conv2d(cat, w.float(), b))
+    out = torch.zeros(B, H, H, 24, dtype=torch.bfloat16, device=DEV)
+    sm = _nhwc(small).to(DEV); sk = _nhwc(skip).to(DEV)
+    yv.conv2d(yv.view(sm, 0, 32, up=1), yv.view(sk, 0, 16), B, H, H, 1, 1, w.reshape(24, 48).contiguous().to(DEV),
+              b.to(DEV), out, 0, yv.EPI_SILU)
+    assert rel_l2(out.permute(0, 3, 1, 2).float().cpu(), ref) < 4e-3
+    # bottleneck shortcut: y = x + SiLU(conv(x)) reading / writing channel slices of one buffer
+    buf = bf(torch.randn(B, H, H, 64, generator=g)).to(DEV)
+    w3 = bf(torch.randn(16, 16, 3, 3, generator=g) * 0.1); b3 = torch.randn(16, generator=g) * 0.1
+    xin = buf[..., 16:32].permute(0, 3, 1, 2).float().cpu()
+    ref3 = xin + F.silu(F.conv2d(xin, w3.float(), b3, padding=1))
+    yv.conv2d(yv.view(buf, 16, 16), None, B, H, H, 3, 1, w3.permute(0, 2, 3, 1).reshape(16, 144).contiguous().to(DEV),
+              b3.to(DEV), buf, 32, yv.EPI_SILU | yv.EPI_RES_BF16, res=buf, res_c_off=16)
+    assert rel_l2(buf[..., 32:48].permute(0, 3, 1, 2).float().cpu(), ref3) < 4e-3
+
+
+def test_layernorm(yv):
+    g = torch.Generator().manual_seed(1)
+    for D, rows in ((768, 197 * 2), (1024, 33), (128, 10)):
+        x = torch.randn(rows, D, generator=g) * 3 + 0.5
+        ga = 1 + 0.1 * torch.randn(D, generator=g); be = 0.1 * torch.randn(D, generator=g)
+        ref = F.layer_norm(x, (D,), ga, be, eps=1e-6)
+        y = torch.zeros(rows, D, dtype=torch.bfloat16, device=DEV)
+        yv.layernorm(x.to(DEV), ga.to(DEV), be.to(DEV), y, rows, D, D, D)
+        # f32 statistics; error = bf16 rounding of the output (|y| <~ 4 -> 2^-7 abs)
+        assert torch.allclose(y.cpu().float(), ref, atol=2e-2, rtol=8e-3)
+        assert rel_l2(y.cpu().float(), ref) < 3e-3
+    # strided rows (cls token only) + dynamic count
+    x = torch.randn(6 * 5, 128, generator=g)
+    y = torch.zeros(6, 128, dtype=torch.bfloat16, device=DEV)
+    cnt = torch.tensor([4], dtype=torch.int32, device=DEV)
+    yv.layernorm(x.to(DEV), torch.ones(128, device=DEV), torch.zeros(128, device=DEV), y, 6, 128, 5 * 128, 128,
+                 count_dev=cnt, rows_per_count=1)
+    ref = F.layer_norm(x.view(6, 5, 128)[:, 0], (128,), eps=1e-6)
+    assert rel_l2(y.cpu().float()[:4], ref[:4]) < 3e-3 and float(y[4:].float().abs().sum()) == 0
+
+
+@pytest.mark.parametrize("R,N,H", [(3, 197, 12), (2, 5, 2), (2, 50, 2), (1, 256, 3), (2, 33, 1), (1, 64, 2)])
+def test_attention(yv, R, N, H):
+    g = torch.Generator().manual_seed(R * 7 + N)
+    D = H * 64
+    qkv = bf(torch.randn(R * N, 3 * D, generator=g) * 1.5)
+    t = qkv.float().view(R, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    att = ((t[0] * 0.125) @ t[1].transpose(-2, -1)).softmax(-1)
+    ref = (att @ t[2]).transpose(1, 2).reshape(R * N, D)
+    out = torch.zeros(R * N, D, dtype=torch.bfloat16, device=DEV)
+    yv.attention(qkv.to(DEV), R, N, H, out)
+    # P is rounded to bf16 before P.V and the output to bf16: 2^-8 relative each
+    assert rel_l2(out.cpu().float(), ref) < 8e-3
+    assert torch.allclose(out.cpu().float(), ref, atol=3e-2, rtol=2e-2)
+
+
+def test_attention_softmax_spike(yv):
+    # one key dominates one query row (forces large max subtraction); result must stay exact-ish
+    R, N, H = 1, 197, 1
+    g = torch.Generator().manual_seed(5)
+    qkv = bf(torch.randn(N, 192, generator=g))
+    qkv[7, :64] = 8.0; qkv[100, 64:128] = 8.0
+    t = qkv.float().view(1, N, 3, 1, 64).permute(2, 0, 3, 1, 4)
+    ref = (((t[0] * 0.125) @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(N, 64)
+    out = torch.zeros(N, 64, dtype=torch.bfloat16, device=DEV)
+    yv.attention(qkv.to(DEV), R, N, H, out)
+    assert torch.allclose(out.cpu().float(), ref, atol=3e-2, rtol=2e-2)
+    assert torch.allclose(out.cpu().float()[7], qkv.float()[100, 128:], atol=2e-2)
+
+
+def test_wrapper_head_golden(yv, golden_dir):
+    import numpy as np
+    z = np.load(golden_dir + "/G6_wrapper.npz")
+    feats = torch.from_numpy(z["feats"]); exp = torch.from_numpy(z["out"])
+    R = feats.shape[0]
+    fpad = torch.zeros(R, 1024); fpad[:, :1000] = feats
+    logits = torch.zeros(R, 5, device=DEV); labels = torch.zeros(R, dtype=torch.int32, device=DEV)
+    w = {k: torch.from_numpy(z[k]).to(DEV) for k in ("fc__1__weight", "fc__1__bias", "fc__3__weight", "fc__3__bias")}
+    yv.wrapper_head(fpad.to(DEV), w["fc__1__weight"], w["fc__1__bias"], w["fc__3__weight"], w["fc__3__bias"], R, 5,
+                    logits, labels)
+    assert torch.allclose(logits.cpu(), exp, atol=1e-5, rtol=1e-5)          # f32, summation order only
+    assert labels.cpu().tolist() == exp.argmax(1).tolist()
+    # ensemble: mean of two identical models == the model
+    yv.wrapper_head(fpad.to(DEV), w["fc__1__weight"], w["fc__1__bias"], w["fc__3__weight"], w["fc__3__bias"], R, 5,
+                    logits, labels, scale=0.5, accumulate=False)
+    yv.wrapper_head(fpad.to(DEV), w["fc__1__weight"], w["fc__1__bias"], w["fc__3__weight"], w["fc__3__bias"], R, 5,
+                    logits, labels, scale=0.5, accumulate=True)
+    assert torch.allclose(logits.cpu(), exp, atol=1e-5, rtol=1e-5)
+
+
+def test_sppf_pool(yv):
+    g = torch.Generator().manual_seed(2)
+    B, H, c = 2, 20, 16
+    buf = torch.zeros(B, H, H, 4 * c, dtype=torch.bfloat16)
+    x = bf(torch.randn(B, H, H, c, generator=g)); buf[..., :c] = x
+    d = buf.to(DEV)
+    yv.sppf_pool(d, c)
+    y = x.float().permute(0, 3, 1, 2)
+    for i in range(1, 4):
+        y = F.max_pool2d(y, 5, 1, 2)
+        assert torch.equal(d[..., i * c:(i + 1) * c].float().cpu(), y.permute(0, 2, 3, 1))    # max is exact
+    assert torch.equal(d[..., :c].cpu(), x)
+
+
+def test_stem_conv(yv):
+    g = torch.Generator().manual_seed(8)
+    B, H = 2, 64
+    img = torch.randint(0, 256, (B, H, H, 3), generator=g, dtype=torch.uint8)
+    w = torch.randn(16, 3, 3, 3, generator=g) * 0.3; b = torch.randn(16, generator=g) * 0.1
+    ref = F.silu(F.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, w, b, stride=2, padding=1))
+    out = torch.zeros(B, H // 2, H // 2, 16, dtype=torch.bfloat16, device=DEV)
+    yv.stem_conv(img.to(DEV), w.permute(0, 2, 3, 1).reshape(16, 27).contiguous().to(DEV), b.to(DEV), out)
+    assert rel_l2(out.permute(0, 3, 1, 2).float().cpu(), ref) < 3e-3

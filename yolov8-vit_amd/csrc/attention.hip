@@ -1,0 +1,182 @@
+// Fused non-causal attention forward for ViT token counts (N <= 256, head dim 64):
+//   O = softmax(Q K^T * scale) V              timm Attention (README.md:21-23), SURVEY.md row B3 / K10.
+//
+// One workgroup per (crop, head); wave w owns query rows [32w, 32w+32).  K (row major)
+// and V^T live whole in LDS (N = 197: 28 KB + 29 KB), so there is no online-softmax
+// rescale: each wave computes its full 32 x N score block in registers.
+//
+// MFMA plan (v_mfma_f32_32x32x16_bf16, accumulators in f32):
+//   S^T tile = K_tile (A: 32 keys x 64 d) . Q^T (B: 64 d x 32 queries)
+//     -> the accumulator has the KEY on the register axis and the QUERY on the lane,
+//        so the softmax row-reduction is in-lane + one lane^32 exchange, and
+//   O^T = V^T (A: 64 d x keys) . P^T (B: keys x 32 queries)
+//     takes the exponentiated accumulator registers directly as its B operand
+//     (registers 8s..8s+7 -> k-step s; k order inside a step is
+//      16s + 8(j>>2) + 4h + (j&3), matched by the V^T fragment addressing): P never
+//     touches LDS.
+//   LDS images: K rows are 128 B with the 16-byte chunk XOR-swizzled by ((row>>1)&7)
+//   (conflict-free ds_read_b128 for the 32-row A fragment); V^T rows are padded to
+//   2*NP+8 bytes (odd multiple of 8 B: conflict-free ds_read_b64 over 32 rows).
+#include "yv_common.h"
+
+namespace {
+
+constexpr int HD = 64;
+
+template <int NT>
+__global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __restrict__ qkv, int N, int H,
+                                                            float scale_log2e, uint16_t* __restrict__ out,
+                                                            const int32_t* __restrict__ r_dev) {
+    constexpr int NP = NT * 32;
+    constexpr int VT_STRIDE = NP * 2 + 8;               // bytes per V^T row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;                            // NP x 128 B
+    unsigned char* Vt = smem + NP * 128;                 // 64 x VT_STRIDE
+    const int r = blockIdx.x / H, hd = blockIdx.x - r * H;
+    if (r_dev && r >= r_dev[0]) return;
+    const int D = H * HD, ld = 3 * D;
+    const uint16_t* base = qkv + (size_t)r * N * ld + hd * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int T = NT * 64;
+
+    // ---- stage K (swizzled rows) and V^T (explicit transpose) -----------------------------
+    for (int it = tid; it < NP * 8; it += T) {
+        const int key = it >> 3, c = it & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < N) {
+            kv = *(const uint4*)(base + (size_t)key * ld + D + c * 8);
+            vv = *(const uint4*)(base + (size_t)key * ld + 2 * D + c * 8);
+        }
+        *(uint4*)(Ks + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = kv;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint16_t val = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+            *(uint16_t*)(Vt + (c * 8 + e) * VT_STRIDE + key * 2) = val;
+        }
+    }
+
+    // ---- Q fragments (B operand), straight from global --------------------------------------
+    const int rl = lane & 31, hh = lane >> 5;
+    const int q = wave * 32 + rl;
+    const int qc = q < N ? q : N - 1;
+    bf16x8 fq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fq[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
+    __syncthreads();
+
+    // ---- S^T = K . Q^T ------------------------------------------------------------------------
+    f32x16 s[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+        const int row = kt * 32 + rl;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + hh;
+            const bf16x8 fk = *(const bf16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], s[kt], 0, 0, 0);
+        }
+    }
+
+    // ---- softmax over keys (register axis + lane^32) -----------------------------------------
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            const float v = key < N ? s[kt][e] : -INFINITY;
+            s[kt][e] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mb = mx * scale_log2e;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = exp2f(s[kt][e] * scale_log2e - mb);
+            s[kt][e] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 32, 64);
+
+    // ---- O^T = V^T . P^T ------------------------------------------------------------------------
+    f32x16 o[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 fp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fp[j] = (__bf16)s[kt][8 * st + j];
+            const int key0 = kt * 32 + 16 * st + 4 * hh;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const unsigned char* vr = Vt + (mt * 32 + rl) * VT_STRIDE + key0 * 2;
+                const uint2 lo = *(const uint2*)vr;
+                const uint2 hi = *(const uint2*)(vr + 16);
+                const u32x4 pk = {lo.x, lo.y, hi.x, hi.y};
+                const bf16x8 fv = __builtin_bit_cast(bf16x8, pk);
+                o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fp, o[mt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise and store: lane owns d = 32mt + 8g + 4hh .. +3 of its query -------------
+    if (q < N) {
+        const float inv = 1.0f / l;
+        uint16_t* orow = out + ((size_t)r * N + q) * D + hd * HD;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = mt * 32 + 8 * g4 + 4 * hh;
+                *(uint2*)(orow + d) = make_uint2(pack_bf16x2(o[mt][4 * g4] * inv, o[mt][4 * g4 + 1] * inv),
+                                                 pack_bf16x2(o[mt][4 * g4 + 2] * inv, o[mt][4 * g4 + 3] * inv));
+            }
+    }
+}
+
+template <int NT>
+int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t* out, const int32_t* r_dev,
+                hipStream_t st) {
+    constexpr int NP = NT * 32;
+    const size_t lds = (size_t)NP * 128 + 64 * (size_t)(NP * 2 + 8);
+    auto kern = attention_kernel<NT>;
+    if (lds > 65536 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return YV_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(R * H), dim3(NT * 64), lds, st, qkv, N, H, scale * 1.4426950408889634f, out, r_dev);
+    return yv_launch_status();
+}
+
+}  // namespace
+
+extern "C" int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev,
+                            void* stream) {
+    if (!qkv || !out || R < 0 || N <= 0 || H <= 0) return YV_ERR_ARG;
+    if (N > 256) return YV_ERR_LIMIT;
+    if (R == 0) return YV_OK;
+    const uint16_t* q = (const uint16_t*)qkv;
+    uint16_t* o = (uint16_t*)out;
+    hipStream_t st = (hipStream_t)stream;
+    const int nt = (N + 31) / 32;
+    switch (nt) {
+        case 1: return launch_attn<1>(q, R, N, H, scale, o, r_dev, st);
+        case 2: return launch_attn<2>(q, R, N, H, scale, o, r_dev, st);
+        case 3: return launch_attn<3>(q, R, N, H, scale, o, r_dev, st);
+        case 4: return launch_attn<4>(q, R, N, H, scale, o, r_dev, st);
+        case 5: return launch_attn<5>(q, R, N, H, scale, o, r_dev, st);
+        case 6: return launch_attn<6>(q, R, N, H, scale, o, r_dev, st);
+        case 7: return launch_attn<7>(q, R, N, H, scale, o, r_dev, st);
+        default: return launch_attn<8>(q, R, N, H, scale, o, r_dev, st);
+    }
+}

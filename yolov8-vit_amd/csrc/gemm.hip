@@ -47,6 +47,7 @@ struct GemmArgs {
     int tok;
     int flags;
     const int32_t* m_dev;
+    int m_mul;
     int tiles_m, tiles_n;
 };
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     int M = g.M;
-    if (g.m_dev) { int md = g.m_dev[0]; M = md < M ? md : M; }
+    if (g.m_dev) { long long md = (long long)g.m_dev[0] * g.m_mul; M = md < M ? (int)md : M; }
 
     // XCD-aware bijective remap of the 1-D grid
     int bid = blockIdx.x;
@@ -274,7 +275,7 @@ int dispatch(GemmArgs& g, hipStream_t st) {
 }  // namespace
 
 extern "C" int yv_linear(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out,
-                         int ldo, const float* pos, int tok, int flags, const int32_t* m_dev, void* stream) {
+                         int ldo, const float* pos, int tok, int flags, const int32_t* m_dev, int m_mul, void* stream) {
     if (!A || !W || !out || M < 0 || N <= 0 || K <= 0) return YV_ERR_ARG;
     if ((K & 7) || (lda & 7) || (N & 3) || (ldo & 3)) return YV_ERR_ARG;            // 16-byte operand chunks, 4-wide stores
     if ((flags & YV_EPI_BIAS) && !bias) return YV_ERR_ARG;
@@ -285,7 +286,7 @@ extern "C" int yv_linear(const void* A, int lda, const void* W, const float* bia
     GemmArgs g = {};
     g.a0 = (const uint16_t*)A; g.lda0 = lda; g.c0 = K;
     g.w = (const uint16_t*)W; g.bias = bias; g.M = M; g.N = N; g.K = K;
-    g.out = out; g.ldo = ldo; g.pos = pos; g.tok = tok; g.flags = flags; g.m_dev = m_dev;
+    g.out = out; g.ldo = ldo; g.pos = pos; g.tok = tok; g.flags = flags; g.m_dev = m_dev; g.m_mul = m_mul;
     g.ksize = 1; g.stride = 1;
     return dispatch<0>(g, (hipStream_t)stream);
 }

@@ -1,0 +1,143 @@
+// Wave-reduction / latency kernels around the ViT GEMMs (SURVEY.md rows B3 tail, B4):
+//   yv_layernorm     timm blocks.*.norm1/2 and the final norm (eps 1e-6; README.md:21-29): f32 stream -> bf16
+//   yv_cls_rows      cls_token + pos_embed[0] rows of the token stream (README.md:13-17)
+//   yv_wrapper_head  Network_Wrapper.fc: ReLU -> Linear(1000,128) -> ReLU -> Linear(128,nc), ensemble mean, argmax
+//                    (utils/utils.py:64-72, utils/trainClass.py:112)
+// LayerNorm is HBM-bound (4 B read + 2 B written per element): one wave per row, the
+// row lives in registers (two-pass mean / variance in f32), 16-byte loads, 8-byte stores.
+#include "yv_common.h"
+
+namespace {
+
+constexpr int LN_MAXC = 4;          // float4 chunks per lane -> D <= 1024
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, size_t ldx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int D, float eps, uint16_t* __restrict__ y, size_t ldy,
+                                                        const int32_t* __restrict__ count_dev, int rows_per_count) {
+    if (count_dev) {
+        long long r = (long long)count_dev[0] * rows_per_count;
+        rows = r < rows ? (int)r : rows;
+    }
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    const int nch = D >> 2;                       // float4 chunks in the row
+    float4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nch) {
+            v[i] = ((const float4*)xr)[c];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    uint16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float4 g = ((const float4*)gamma)[c], b = ((const float4*)beta)[c];
+            const float o0 = (v[i].x - mean) * rstd * g.x + b.x, o1 = (v[i].y - mean) * rstd * g.y + b.y;
+            const float o2 = (v[i].z - mean) * rstd * g.z + b.z, o3 = (v[i].w - mean) * rstd * g.w + b.w;
+            ((uint2*)yr)[c] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        }
+    }
+}
+
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, int R, int tok, int D,
+                                float* __restrict__ x) {
+    const int r = blockIdx.x;
+    float* o = x + (size_t)r * (tok + 1) * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) o[i] = cls[i] + pos[i];
+}
+
+constexpr int WH_FEAT = 1000, WH_HID = 128, WH_MAX_NC = 32;
+
+__global__ __launch_bounds__(256) void wrapper_head_kernel(const float* __restrict__ feats, int ldf,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           int nc, float scale, int accumulate,
+                                                           float* __restrict__ logits, int32_t* __restrict__ labels,
+                                                           const int32_t* __restrict__ r_dev) {
+    __shared__ float f[WH_FEAT];
+    __shared__ float h[WH_HID];
+    __shared__ float lg[WH_MAX_NC];
+    const int r = blockIdx.x;
+    if (r_dev && r >= r_dev[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < WH_FEAT; i += 256) f[i] = fmaxf(feats[(size_t)r * ldf + i], 0.f);     // ReLU
+    __syncthreads();
+    for (int u = wave * 32; u < wave * 32 + 32; ++u) {
+        const float* wr = w1 + (size_t)u * WH_FEAT;
+        float s = 0.f;
+        for (int k = lane; k < WH_FEAT; k += 64) s = fmaf(f[k], wr[k], s);
+        s = wave_sum(s);
+        if (lane == 0) h[u] = fmaxf(s + b1[u], 0.f);                                             // ReLU
+    }
+    __syncthreads();
+    if (tid < nc) {
+        const float* wr = w2 + (size_t)tid * WH_HID;
+        float s = 0.f;
+        for (int k = 0; k < WH_HID; ++k) s = fmaf(h[k], wr[k], s);
+        s = (s + b2[tid]) * scale;
+        float* o = logits + (size_t)r * nc + tid;
+        if (accumulate) s += *o;
+        *o = s;
+        lg[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0;
+        float bv = lg[0];
+        for (int c = 1; c < nc; ++c)
+            if (lg[c] > bv) { bv = lg[c]; best = c; }
+        labels[r] = best;
+    }
+}
+
+}  // namespace
+
+extern "C" int yv_layernorm(const float* x, size_t ldx, const float* gamma, const float* beta, int rows, int D,
+                            float eps, void* y, size_t ldy, const int32_t* count_dev, int rows_per_count,
+                            void* stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || D <= 0) return YV_ERR_ARG;
+    if ((D & 3) || (ldx & 3) || (ldy & 3)) return YV_ERR_ARG;
+    if (D > LN_MAXC * 256) return YV_ERR_LIMIT;
+    if (rows == 0) return YV_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                       rows, D, eps, (uint16_t*)y, ldy, count_dev, rows_per_count);
+    return yv_launch_status();
+}
+
+extern "C" int yv_cls_rows(const float* cls, const float* pos, int R, int tok, int D, float* x, void* stream) {
+    if (!cls || !pos || !x || R < 0 || tok <= 0 || D <= 0) return YV_ERR_ARG;
+    if (R == 0) return YV_OK;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, cls, pos, R, tok, D, x);
+    return yv_launch_status();
+}
+
+extern "C" int yv_wrapper_head(const float* feats, int ldf, const float* w1, const float* b1, const float* w2,
+                               const float* b2, int R, int nc, float scale, int accumulate, float* logits,
+                               int32_t* labels, const int32_t* r_dev, void* stream) {
+    if (!feats || !w1 || !b1 || !w2 || !b2 || !logits || !labels || R < 0 || ldf < WH_FEAT) return YV_ERR_ARG;
+    if (nc <= 0 || nc > WH_MAX_NC) return YV_ERR_LIMIT;
+    if (R == 0) return YV_OK;
+    hipLaunchKernelGGL(wrapper_head_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, feats, ldf, w1, b1, w2, b2, nc,
+                       scale, accumulate, logits, labels, r_dev);
+    return yv_launch_status();
+}

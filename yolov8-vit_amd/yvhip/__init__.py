@@ -53,8 +53,8 @@ _SIGS = {
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "yv_conv2d": (_i, [C.POINTER(yv_view), C.POINTER(yv_view), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
                        _i, _vp]),
-    "yv_linear": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
-    "yv_layernorm": (_i, [_vp, _sz, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _vp]),
+    "yv_linear": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "yv_layernorm": (_i, [_vp, _sz, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _i, _vp]),
     "yv_attention": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "yv_cls_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "yv_wrapper_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
@@ -242,3 +242,80 @@ def sgd_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, momen
     _chk_dev(p, g, m)
     check(lib.yv_sgd_step(_p(p), _p(g), _p(m), p.numel(), float(lr), float(momentum), float(weight_decay),
                           1 if first else 0, _st()), "yv_sgd_step")
+
+
+# ------------------------------------------------------------- dense math
+EPI_BIAS, EPI_SILU, EPI_GELU, EPI_RES_F32, EPI_RES_BF16, EPI_OUT_F32, EPI_POSEMB = 1, 2, 4, 8, 16, 32, 64
+
+
+def view(t: torch.Tensor, c_off: int, c: int, up: int = 0) -> "yv_view":
+    """NHWC bf16 tensor (B,H,W,ld) -> operand view of channels [c_off, c_off+c)."""
+    assert t.dtype == torch.bfloat16 and t.is_cuda and t.is_contiguous()
+    return yv_view(C.c_void_p(t.data_ptr() + 2 * c_off), t.shape[-1], c, up)
+
+
+def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, flags: int = 0,
+           pos: Optional[torch.Tensor] = None, tok: int = 0, m_dev: Optional[torch.Tensor] = None, m_mul: int = 1,
+           M: Optional[int] = None):
+    """out[M,N] (+)= a[M,K] @ w[N,K]^T with the fused epilogue selected by `flags`."""
+    _chk_dev(a, w, bias, out, pos, m_dev)
+    Mr = a.shape[0] if M is None else M
+    K = a.shape[1]
+    N = w.shape[0]
+    assert w.shape[1] == K and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    if bias is not None:
+        flags |= EPI_BIAS
+    check(lib.yv_linear(_p(a), a.stride(0), _p(w), _p(bias), Mr, N, K, _p(out), out.stride(0), _p(pos), tok, flags,
+                        _p(m_dev), m_mul, _st()), "yv_linear")
+    return out
+
+
+def conv2d(in0: "yv_view", in1: Optional["yv_view"], B: int, Hout: int, Wout: int, ksize: int, stride: int,
+           weight: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, out_c_off: int, flags: int,
+           res: Optional[torch.Tensor] = None, res_c_off: int = 0):
+    """Conv2d + bias (+SiLU ...) ; `out` is a (B,Hout,Wout,ld) tensor, written at channel offset out_c_off."""
+    Cout = weight.shape[0]
+    esz = 4 if (flags & EPI_OUT_F32) else 2
+    optr = C.c_void_p(out.data_ptr() + esz * out_c_off)
+    rptr = None if res is None else C.c_void_p(res.data_ptr() + 2 * res_c_off)
+    check(lib.yv_conv2d(C.byref(in0), C.byref(in1) if in1 is not None else None, B, Hout, Wout, ksize, stride,
+                        _p(weight), _p(bias), Cout, optr, out.shape[-1], rptr,
+                        0 if res is None else res.shape[-1], flags | EPI_BIAS, _st()), "yv_conv2d")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor, rows: int, D: int,
+              ldx: int, ldy: int, eps: float = 1e-6, count_dev: Optional[torch.Tensor] = None,
+              rows_per_count: int = 1):
+    check(lib.yv_layernorm(_p(x), ldx, _p(gamma), _p(beta), rows, D, float(eps), _p(y), ldy, _p(count_dev),
+                           rows_per_count, _st()), "yv_layernorm")
+    return y
+
+
+def attention(qkv: torch.Tensor, R: int, N: int, H: int, out: torch.Tensor, scale: Optional[float] = None,
+              r_dev: Optional[torch.Tensor] = None):
+    _chk_dev(qkv, out, r_dev)
+    check(lib.yv_attention(_p(qkv), R, N, H, float(64 ** -0.5 if scale is None else scale), _p(out), _p(r_dev),
+                           _st()), "yv_attention")
+    return out
+
+
+def cls_rows(cls: torch.Tensor, pos: torch.Tensor, R: int, tok: int, D: int, x: torch.Tensor):
+    check(lib.yv_cls_rows(_p(cls), _p(pos), R, tok, D, _p(x), _st()), "yv_cls_rows")
+
+
+def wrapper_head(feats: torch.Tensor, w1, b1, w2, b2, R: int, nc: int, logits: torch.Tensor, labels: torch.Tensor,
+                 scale: float = 1.0, accumulate: bool = False, r_dev: Optional[torch.Tensor] = None):
+    check(lib.yv_wrapper_head(_p(feats), feats.stride(0), _p(w1), _p(b1), _p(w2), _p(b2), R, nc, float(scale),
+                              1 if accumulate else 0, _p(logits), _p(labels), _p(r_dev), _st()), "yv_wrapper_head")
+
+
+def sppf_pool(buf: torch.Tensor, c: int):
+    B, H, W, ld = buf.shape
+    check(lib.yv_sppf_pool(_p(buf), B, H, W, ld, c, _st()), "yv_sppf_pool")
+
+
+def stem_conv(images: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out: torch.Tensor):
+    B, H, W, _ = images.shape
+    check(lib.yv_stem_conv(_p(images), B, H, W, _p(weight), _p(bias), weight.shape[0], _p(out), out.shape[-1],
+                           _st()), "yv_stem_conv")
