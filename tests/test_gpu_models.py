@@ -1,0 +1,78 @@
+"""GPU parity of the two network engines against the fp32 CPU oracle (parity UNPINNED for the
+third-party math - see oracle/vit.py, oracle/yolo.py headers).  Tolerance:
+bf16 path vs fp32 oracle - rel-L2 <= 2e-2 on logits / raw head outputs."""
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle import vit as ov
+from oracle import yolo as oy
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("name,R", [("vit_tiny_test", 3), ("vit_base_patch16_224", 2)])
+def test_vit_engine_vs_oracle(name, R):
+    from yvhip import engines
+    sd = ov.init_wrapper_state(name, seed=11)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(R, 3, 224, 224, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    ref_feats = ov.vit_forward(sd, x, name)
+    ref_logits = ov.wrapper_head(sd, ref_feats)
+    eng = engines.VitEngine(sd, name, 5)
+    P = eng.P
+    pm = torch.cat([torch.from_numpy(ob.patchify(x[r].numpy(), P)) for r in range(R)]).to(torch.bfloat16).to(DEV)
+    cap = R + 1                                      # one spare slot: dynamic count leaves it untouched
+    buf = eng.patch_buffer(cap)
+    buf[:pm.shape[0]] = pm
+    cnt = torch.tensor([R], dtype=torch.int32, device=DEV)
+    feats = eng.backbone(buf, cap, cnt)
+    logits = torch.zeros(cap, 5, device=DEV); labels = torch.full((cap,), -1, dtype=torch.int32, device=DEV)
+    eng.head(feats, cap, logits, labels, count=cnt)
+    torch.cuda.synchronize()
+    assert rel_l2(feats[:R, :1000].cpu(), ref_feats) < 2e-2
+    assert rel_l2(logits[:R].cpu(), ref_logits) < 2e-2
+    assert float(feats[:R, 1000:].abs().sum()) == 0
+    assert int(labels[R]) == -1 and float(logits[R].abs().sum()) == 0
+    margin = ref_logits.topk(2, 1).values
+    sure = (margin[:, 0] - margin[:, 1]) > 0.05 * ref_logits.abs().max()
+    assert labels[:R].cpu()[sure].tolist() == ref_logits.argmax(1)[sure].tolist()
+
+
+@pytest.mark.parametrize("scale,nc,size,B", [("n", 5, 128, 2), ("n", 5, 640, 1), ("s", 80, 64, 1), ("m", 80, 64, 1)])
+def test_yolo_engine_vs_oracle(scale, nc, size, B):
+    from yvhip import engines
+    sd = oy.init_state(scale, nc, seed=7)
+    g = torch.Generator().manual_seed(2)
+    img = torch.randint(0, 256, (B, size, size, 3), generator=g, dtype=torch.uint8)
+    raw, outs = oy.forward_raw(sd, oy.blob(img), scale, nc, return_feats=True)
+    eng = engines.YoloEngine(sd, scale, nc, size)
+    box_l, cls_l = eng.forward_raw(img.to(DEV))
+    torch.cuda.synchronize()
+    bufs = eng._buffers(B)
+    # intermediate feature maps (bf16 activations vs fp32 oracle)
+    for idx in (0, 1, 2, 4, 6, 9, 12, 15, 18, 21):
+        got = bufs["out"][idx].float().permute(0, 3, 1, 2).cpu()
+        assert rel_l2(got, outs[idx]) < 2e-2, idx
+    a0 = 0
+    for s, st in enumerate((8, 16, 32)):
+        w = size // st
+        part = raw[:, :, a0:a0 + w * w].reshape(B, 64 + nc, w, w)
+        assert rel_l2(box_l[s].permute(0, 3, 1, 2).cpu(), part[:, :64]) < 2e-2
+        assert rel_l2(cls_l[s][..., :nc].permute(0, 3, 1, 2).cpu(), part[:, 64:]) < 2e-2
+        a0 += w * w
+    eb, es = oy.decode(raw, nc, size)
+    gb, gs = eng(img.to(DEV))
+    assert rel_l2(gs.cpu(), es) < 2e-2
+    assert float((gb.cpu() - eb).abs().max()) < 0.02 * size       # pixels; DFL expectation of bf16 logits
+
+
+def test_yolo_kat_param_count():
+    from yvhip import engines
+    tot = sum(ci * co * k * k + co for _, ci, co, k in engines.yolo_conv_keys("n", 5)) + 16
+    assert tot == 3006623                                           # KAT-1, test.ipynb:12
