@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s end-to-end (640 -> 224 detect + classify), BASELINE.json configs[1]:
+YOLOv8n + ViT-B/16, 640x640, batch 32 per GPU, bf16, synthetic data, random-init weights.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; images shard across ranks with no
+   data-path collective -> "scaling": "weak")
+
+One step = the whole hot path over one batch already resident in HBM:
+stem+backbone+neck+head -> DFL decode -> EfficientNMS(0.25/0.65/100) -> restore/filter(0.35)/int ->
+custom_nms(0.45) dedupe -> inflate -> crop+nearest-resize+normalize -> ViT-B/16 -> wrapper head -> argmax.
+Crops per image are capped at --crops (default 4, SURVEY.md 8(d) "fixed-R mode") so the
+classifier work per step is deterministic; the cap is part of the reported config.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "yolov8-vit_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0        # bf16 dense, MI355X_MICROARCH.md chip table
+
+
+def cpu_baseline(yolo_sd, vit_sd, vit_name, crops, budget_s=20.0, max_images=8):
+    """The oracle (CPU restatement, fp32, batch-1 loop) timed on this box's host cores."""
+    from oracle import pipeline as op
+    g = torch.Generator().manual_seed(1234)
+    imgs = torch.randint(0, 256, (max_images + 1, 640, 640, 3), generator=g, dtype=torch.uint8)
+    with torch.no_grad():
+        op.run_image(imgs[0], yolo_sd, [vit_sd], vit_name, max_crops=crops)      # warm-up (page-in, thread pool)
+        n, t0 = 0, time.perf_counter()
+        while n < max_images and (time.perf_counter() - t0) < budget_s:
+            op.run_image(imgs[n + 1], yolo_sd, [vit_sd], vit_name, max_crops=crops)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} synthetic 640x640 images, batch-1 fp32 loop, {crops} crops/image, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--crops", type=int, default=4, help="crops classified per image (cap)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import yvhip
+    from yvhip import engines
+    from yvhip.pipeline import DetectClassifyPipeline
+
+    vit_name = "vit_base_patch16_224"
+    yolo_sd = engines.init_yolo_state("n", 5, seed=42, head_gain=4.0)
+    vit_sd = engines.init_vit_wrapper_state(vit_name, 5, seed=42)
+    yolo = engines.YoloEngine(yolo_sd, "n", 5, 640, device=str(dev))
+    vit = engines.VitEngine(vit_sd, vit_name, 5, device=str(dev))
+    B, R = args.batch, args.crops
+    pipe = DetectClassifyPipeline(yolo, [vit], max_crops_per_image=R)
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = torch.randint(0, 256, (B, 640, 640, 3), generator=g, dtype=torch.uint8).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(max(args.warmup, 1)):
+        out = pipe(images)
+    torch.cuda.synchronize()
+    crops_step = int(out["crop_total"][0])
+
+    # HIP events around every launch of the dominant kernel (the 128x128 MFMA GEMM instance)
+    recs = []
+    yvhip.LINEAR_HOOK = lambda M, N, K, e0, e1: recs.append((2.0 * M * N * K, e0, e1))
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe(images)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    yvhip.LINEAR_HOOK = None
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    if rank == 0:
+        flops = sum(f for f, _, _ in recs)
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs)
+        n_launch = len(recs)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("igemm_linear_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "images/sec end-to-end (640->224 detect+classify)",
+            "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "YOLOv8n(nc=5)+ViT-B/16 end-to-end inference, 640x640, bf16 "
+                                   "(BASELINE.json configs[1])", "batch_per_gpu": B, "global_batch": B * world,
+                       "crops_per_image": R, "crops_per_step_rank0": crops_step, "parallelism": f"dp{world}",
+                       "weights": "random-init, seed 42"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "igemm_kernel<0,128,128,2,2> (ViT linears)", "launches": n_launch,
+                         "avg_launch_us": ms * 1e3 / max(n_launch, 1),
+                         "alg_flop_per_launch": flops / max(n_launch, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(yolo_sd, vit_sd, vit_name, R)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

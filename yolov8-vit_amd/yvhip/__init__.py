@@ -246,6 +246,7 @@ def sgd_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, momen
 
 # ------------------------------------------------------------- dense math
 EPI_BIAS, EPI_SILU, EPI_GELU, EPI_RES_F32, EPI_RES_BF16, EPI_OUT_F32, EPI_POSEMB = 1, 2, 4, 8, 16, 32, 64
+LINEAR_HOOK = None      # callable(M, N, K, start_event, end_event) or None
 
 
 def view(t: torch.Tensor, c_off: int, c: int, up: int = 0) -> "yv_view":
@@ -265,8 +266,15 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
     assert w.shape[1] == K and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
     if bias is not None:
         flags |= EPI_BIAS
+    hook = LINEAR_HOOK
+    if hook is not None:                     # bench.py: HIP events around the launch, on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.yv_linear(_p(a), a.stride(0), _p(w), _p(bias), Mr, N, K, _p(out), out.stride(0), _p(pos), tok, flags,
                         _p(m_dev), m_mul, _st()), "yv_linear")
+    if hook is not None:
+        e1.record()
+        hook(Mr, N, K, e0, e1)
     return out
 
 
