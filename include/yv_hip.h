@@ -38,6 +38,9 @@ int yv_version(void);
 const char* yv_error_string(int code);
 /* 1 if the current HIP device is gfx950, 0 otherwise, <0 on HIP error. */
 int yv_device_is_gfx950(void);
+/* Tuning knobs (process-wide, not part of the reference surface): "linear_variant" (0 register-staged
+ * 128x128, 1 LDS-DMA 128x128, 2 256x128, 3 256x256, 4 128x256), "linear_group_m" (M tiles per L2 group). */
+int yv_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------ boxes */
 

@@ -18,11 +18,15 @@
 //   materialised.
 //   blockIdx is remapped so that the 8 XCDs each walk contiguous N tiles of the same
 //   M tile (activation rows stay in that XCD's L2).
+#include <string.h>
 #include "yv_common.h"
 
 namespace {
 
 constexpr int BK = 64;            // bf16 elements per K step
+int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
+int g_opt_group_m = 8;
+int g_opt_staged = 1;
 constexpr int THREADS = 256;
 
 struct GemmArgs {
@@ -49,10 +53,191 @@ struct GemmArgs {
     const int32_t* m_dev;
     int m_mul;
     int tiles_m, tiles_n;
+    int group_m;
+    int staged;                  // coalesced LDS-staged epilogue usable (alignment / width checked on the host)
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU; erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output step)
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-z * z);          // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+
+template <int MF, int NF>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[NF][MF], int M, int m0, int n0, int wrow_m,
+                                         int wrow_n, int fr, int fq) {
+    // ---- epilogue: lane owns channels n..n+3 of row m --------------------------------------
+    const int flags = g.flags;
+#pragma unroll
+    for (int j = 0; j < MF; ++j) {
+        const int m = m0 + wrow_m + j * 16 + fr;
+        if (m >= M) continue;
+        long long orow = m;
+        const float* posrow = nullptr;
+        if (flags & YV_EPI_POSEMB) {
+            const int r = m / g.tok, t = m - r * g.tok;
+            orow = (long long)r * (g.tok + 1) + 1 + t;
+            posrow = g.pos + (long long)(1 + t) * g.N;
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int n = n0 + wrow_n + i * 16 + fq * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (flags & YV_EPI_BIAS) {
+                const float4 b = *(const float4*)(g.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (flags & YV_EPI_SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
+            }
+            if (flags & YV_EPI_GELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+            }
+            if (flags & YV_EPI_RES_BF16) {
+                const uint2 rr = *(const uint2*)(g.res + orow * g.ldres + n);
+                v[0] += bf16_to_f32((uint16_t)(rr.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rr.x >> 16));
+                v[2] += bf16_to_f32((uint16_t)(rr.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rr.y >> 16));
+            }
+            if (posrow) {
+                const float4 pp = *(const float4*)(posrow + n);
+                v[0] += pp.x; v[1] += pp.y; v[2] += pp.z; v[3] += pp.w;
+            }
+            if (flags & (YV_EPI_OUT_F32 | YV_EPI_RES_F32)) {
+                float* o = (float*)g.out + orow * g.ldo + n;
+                if (flags & YV_EPI_RES_F32) {
+                    const float4 x = *(const float4*)o;
+                    v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+                }
+                *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint16_t* o = (uint16_t*)g.out + orow * g.ldo + n;
+                *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+    }
+}
+
+
+// Coalesced epilogue for 64-column wave tiles (NF == 4).  The ablation of the first version showed
+// the direct epilogue (8-byte stores, 32-byte row segments) costing 41 % of a K = 768 GEMM: the
+// output left at ~2 TB/s.  Here each wave transposes its tile through a private, XOR-swizzled LDS
+// slab (reusing the main-loop buffers after the loop's last barrier) and writes whole 128-byte
+// (bf16) / 256-byte (f32) row segments with 16-byte stores; residual reads are coalesced the same way.
+template <int MF>
+__device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x4 (&acc)[4][MF], int M, int m0, int n0,
+                                                int wrow_m, int wrow_n, int lane, unsigned char* stage) {
+    const int flags = g.flags;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nb = n0 + wrow_n;
+    float4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = nb + i * 16 + fq * 4;
+        bv[i] = ((flags & YV_EPI_BIAS) && n < g.N) ? *(const float4*)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto value = [&](int i, int j, float* v) {
+        v[0] = acc[i][j][0] + bv[i].x; v[1] = acc[i][j][1] + bv[i].y;
+        v[2] = acc[i][j][2] + bv[i].z; v[3] = acc[i][j][3] + bv[i].w;
+        if (flags & YV_EPI_SILU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
+        }
+        if (flags & YV_EPI_GELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+        }
+    };
+    if (!(flags & (YV_EPI_OUT_F32 | YV_EPI_RES_F32))) {
+        // ---- bf16 output: MF*16 rows x 128 B slab -------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < MF; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4];
+                value(i, j, v);
+                const int row = j * 16 + fr, c16 = i * 2 + (fq >> 1);
+                *(uint2*)(stage + row * 128 + ((c16 ^ (row & 7)) << 4) + (fq & 1) * 8) =
+                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+#pragma unroll
+        for (int it = 0; it < MF * 2; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            const int m = m0 + wrow_m + row, n = nb + ch * 8;
+            uint4 pk = *(const uint4*)(stage + row * 128 + ((ch ^ (row & 7)) << 4));
+            if (m < M && n < g.N) {
+                if (flags & YV_EPI_RES_BF16) {
+                    const uint4 rr = *(const uint4*)(g.res + (long long)m * g.ldres + n);
+                    const uint32_t a[4] = {pk.x, pk.y, pk.z, pk.w}, b[4] = {rr.x, rr.y, rr.z, rr.w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[q] = pack_bf16x2(bf16_to_f32((uint16_t)(a[q] & 0xffff)) + bf16_to_f32((uint16_t)(b[q] & 0xffff)),
+                                           bf16_to_f32((uint16_t)(a[q] >> 16)) + bf16_to_f32((uint16_t)(b[q] >> 16)));
+                    pk = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+                *(uint4*)((uint16_t*)g.out + (long long)m * g.ldo + n) = pk;
+            }
+        }
+    } else {
+        // ---- f32 output / residual stream: two passes of MF*8 rows x 256 B ----------------------------
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int jj = 0; jj < MF / 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v[4];
+                    value(i, half * (MF / 2) + jj, v);
+                    const int row = jj * 16 + fr, c16 = i * 4 + fq;
+                    *(float4*)(stage + row * 256 + ((c16 ^ (row & 15)) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+#pragma unroll
+            for (int it = 0; it < MF * 2; ++it) {
+                const int row = it * 4 + (lane >> 4), ch = lane & 15;
+                const int m = m0 + wrow_m + half * (MF * 8) + row, n = nb + ch * 4;
+                float4 v = *(const float4*)(stage + row * 256 + ((ch ^ (row & 15)) << 4));
+                if (m < M && n < g.N) {
+                    long long orow = m;
+                    if (flags & YV_EPI_POSEMB) {
+                        const int r = m / g.tok, t = m - r * g.tok;
+                        orow = (long long)r * (g.tok + 1) + 1 + t;
+                        const float4 pp = *(const float4*)(g.pos + (long long)(1 + t) * g.N + n);
+                        v.x += pp.x; v.y += pp.y; v.z += pp.z; v.w += pp.w;
+                    }
+                    float* o = (float*)g.out + orow * g.ldo + n;
+                    if (flags & YV_EPI_RES_F32) {
+                        const float4 x = *(const float4*)o;
+                        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                    }
+                    *(float4*)o = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MF, int NF>
+__device__ __forceinline__ void finish_tile(const GemmArgs& g, f32x4 (&acc)[NF][MF], int M, int m0, int n0, int wrow_m,
+                                            int wrow_n, int lane, int wave, unsigned char* smem) {
+    if constexpr (NF == 4 && (MF % 2) == 0) {
+        if (g.staged) {          // wave-private slab of MF*16 rows x 128 B inside the (now idle) tile buffers
+            epilogue_staged<MF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, smem + wave * (MF * 16 * 128));
+            return;
+        }
+    }
+    epilogue<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane & 15, lane >> 4);
+}
 
 template <int MODE /*0 linear, 1 conv*/, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
@@ -196,58 +381,139 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns channels n..n+3 of row m --------------------------------------
-    const int flags = g.flags;
-#pragma unroll
-    for (int j = 0; j < MF; ++j) {
-        const int m = m0 + wrow_m + j * 16 + fr;
-        if (m >= M) continue;
-        long long orow = m;
-        const float* posrow = nullptr;
-        if (flags & YV_EPI_POSEMB) {
-            const int r = m / g.tok, t = m - r * g.tok;
-            orow = (long long)r * (g.tok + 1) + 1 + t;
-            posrow = g.pos + (long long)(1 + t) * g.N;
-        }
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int n = n0 + wrow_n + i * 16 + fq * 4;
-            if (n >= g.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (flags & YV_EPI_BIAS) {
-                const float4 b = *(const float4*)(g.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (flags & YV_EPI_SILU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
-            }
-            if (flags & YV_EPI_GELU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
-            }
-            if (flags & YV_EPI_RES_BF16) {
-                const uint2 rr = *(const uint2*)(g.res + orow * g.ldres + n);
-                v[0] += bf16_to_f32((uint16_t)(rr.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rr.x >> 16));
-                v[2] += bf16_to_f32((uint16_t)(rr.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rr.y >> 16));
-            }
-            if (posrow) {
-                const float4 pp = *(const float4*)(posrow + n);
-                v[0] += pp.x; v[1] += pp.y; v[2] += pp.z; v[3] += pp.w;
-            }
-            if (flags & (YV_EPI_OUT_F32 | YV_EPI_RES_F32)) {
-                float* o = (float*)g.out + orow * g.ldo + n;
-                if (flags & YV_EPI_RES_F32) {
-                    const float4 x = *(const float4*)o;
-                    v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
-                }
-                *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                uint16_t* o = (uint16_t*)g.out + orow * g.ldo + n;
-                *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
-        }
+    finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Linear fast path (K % 64 == 0): both tiles go global -> LDS by LDS-DMA (global_load_lds, 16 B per
+// lane, no staging VGPRs, no ds_write pass).  One wave-instruction fills 8 rows x 128 B of the
+// lane-linear LDS image, so the chunk swizzle is applied to the SOURCE address (chunk' ^ (row & 7))
+// and again on the fragment read - the same involution on both sides.  Two LDS buffers; the DMA of
+// K step t+1 is issued before the MFMAs of step t and drained (vmcnt(0)) at the step's only barrier.
+// Rows past the end of a matrix are clamped to its last row: their results are never stored.
+// ---------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WM, int WN, int ABL = 0>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
+    // ABL (diagnostic builds only): 1 no in-loop DMA, 2 no MFMA, 3 no fragment reads, 4 no epilogue
+    constexpr int NW = WM * WN;                                // waves per workgroup
+    constexpr int MF = BM / WM / 16, NF = BN / WN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
+    constexpr int A_INS = BM / (8 * NW), W_INS = BN / (8 * NW);   // wave-instructions per wave per K step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    int M = g.M;
+    if (g.m_dev) { long long md = (long long)g.m_dev[0] * g.m_mul; M = md < M ? (int)md : M; }
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
     }
+    // grouped order inside the XCD's chunk: GM consecutive M tiles share each W tile while it is hot in L2
+    int tm, tn;
+    {
+        const int GM = g.group_m, per = GM * g.tiles_n;
+        const int grp = bid / per, first = grp * GM;
+        const int gsz = (g.tiles_m - first) < GM ? (g.tiles_m - first) : GM;
+        const int in = bid - grp * per;
+        tm = first + in % gsz;
+        tn = in / gsz;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= M) return;
+
+    // per-lane source rows (swizzled chunk) for every DMA instruction of this wave
+    const int lrow = lane >> 3, lch = lane & 7;
+    const uint16_t* a_src[A_INS];
+    const uint16_t* w_src[W_INS];
+#pragma unroll
+    for (int j = 0; j < A_INS; ++j) {
+        const int r = (j * NW + wave) * 8 + lrow;
+        int m = m0 + r;
+        m = m < g.M ? m : g.M - 1;
+        a_src[j] = g.a0 + (long long)m * g.lda0 + ((lch ^ (r & 7)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < W_INS; ++j) {
+        const int r = (j * NW + wave) * 8 + lrow;
+        int n = n0 + r;
+        n = n < g.N ? n : g.N - 1;
+        w_src[j] = g.w + (long long)n * g.K + ((lch ^ (r & 7)) << 3);
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* A = smem + buf * (A_BYTES + W_BYTES);
+        unsigned char* W = A + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < A_INS; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + kt * BK), (lptr_t)(A + (j * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < W_INS; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + kt * BK), (lptr_t)(W + (j * NW + wave) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int wrow_m = wm * (BM / WM), wrow_n = wn * (BN / WN);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const int nk = g.K / BK;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (ABL != 1 && kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        const unsigned char* A = smem + cur * (A_BYTES + W_BYTES);
+        const unsigned char* W = A + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[MF], fw[NF];
+            const int kc = ks * 4 + fq;
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int rr = wrow_m + j * 16 + fr;
+                if (ABL != 3) fa[j] = *(const bf16x8*)(A + rr * 128 + ((kc ^ (rr & 7)) << 4));
+                else { u32x4 z = {(uint32_t)rr, 1u, 2u, 3u}; fa[j] = __builtin_bit_cast(bf16x8, z); }
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int rr = wrow_n + i * 16 + fr;
+                if (ABL != 3) fw[i] = *(const bf16x8*)(W + rr * 128 + ((kc ^ (rr & 7)) << 4));
+                else { u32x4 z = {(uint32_t)rr, 5u, 6u, 7u}; fw[i] = __builtin_bit_cast(bf16x8, z); }
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j)
+                    if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+                    else { asm volatile("" :: "v"(fw[i]), "v"(fa[j])); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (ABL != 4) finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
+    else if (acc[0][0][0] == 12345.678f) finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
+}
+
+template <int BM, int BN, int WM, int WN, int ABL = 0>
+int launch_dma(GemmArgs& g, hipStream_t st) {
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    auto kern = gemm_dma_kernel<BM, BN, WM, WN, ABL>;
+    if (lds > 65536 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return YV_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
+    return yv_launch_status();
 }
 
 template <int MODE, int BM, int BN, int WM, int WN>
@@ -264,6 +530,16 @@ int launch(GemmArgs& g, hipStream_t st) {
     return yv_launch_status();
 }
 
+
+// 16-byte row segments need 8-element (bf16) / 4-element (f32) aligned widths, strides and bases
+bool epi_can_stage(const GemmArgs& g) {
+    const bool f32 = g.flags & (YV_EPI_OUT_F32 | YV_EPI_RES_F32);
+    const int al = f32 ? 4 : 8;
+    if ((g.N % al) || (g.ldo % al) || ((uintptr_t)g.out & 15)) return false;
+    if ((g.flags & YV_EPI_RES_BF16) && ((g.ldres % 8) || ((uintptr_t)g.res & 15))) return false;
+    return true;
+}
+
 template <int MODE>
 int dispatch(GemmArgs& g, hipStream_t st) {
     if (g.N > 64) return launch<MODE, 128, 128, 2, 2>(g, st);
@@ -273,6 +549,14 @@ int dispatch(GemmArgs& g, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int yv_set_option(const char* key, int value) {
+    if (!key) return YV_ERR_ARG;
+    if (!strcmp(key, "linear_variant")) { g_opt_variant = value; return YV_OK; }
+    if (!strcmp(key, "linear_group_m")) { g_opt_group_m = value; return YV_OK; }
+    if (!strcmp(key, "staged_epilogue")) { g_opt_staged = value; return YV_OK; }
+    return YV_ERR_ARG;
+}
 
 extern "C" int yv_linear(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out,
                          int ldo, const float* pos, int tok, int flags, const int32_t* m_dev, int m_mul, void* stream) {
@@ -288,6 +572,25 @@ extern "C" int yv_linear(const void* A, int lda, const void* W, const float* bia
     g.w = (const uint16_t*)W; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.out = out; g.ldo = ldo; g.pos = pos; g.tok = tok; g.flags = flags; g.m_dev = m_dev; g.m_mul = m_mul;
     g.ksize = 1; g.stride = 1;
+    g.staged = g_opt_staged && epi_can_stage(g);
+    g.group_m = g_opt_group_m > 0 ? g_opt_group_m : 8;
+    if ((K % BK) == 0 && N > 64 && g_opt_variant != 0) {
+        int variant = g_opt_variant;
+        // auto (measured on the ViT-B/16 shapes, tools/gemm_bench.py): wide outputs amortise a 256x256 tile
+        // (half the L2->LDS bytes per flop); N = 768 keeps 128x128 (more workgroups, shorter tail)
+        if (variant == 1 && N >= 1536 && M >= 2048) variant = 3;
+        switch (variant) {
+            case 2: return launch_dma<256, 128, 4, 2>(g, (hipStream_t)stream);
+            case 3: return launch_dma<256, 256, 2, 4>(g, (hipStream_t)stream);
+            case 4: return launch_dma<128, 256, 2, 4>(g, (hipStream_t)stream);
+            case 101: return launch_dma<128, 128, 2, 2, 1>(g, (hipStream_t)stream);
+            case 102: return launch_dma<128, 128, 2, 2, 2>(g, (hipStream_t)stream);
+            case 103: return launch_dma<128, 128, 2, 2, 3>(g, (hipStream_t)stream);
+            case 104: return launch_dma<128, 128, 2, 2, 4>(g, (hipStream_t)stream);
+            case 10: return launch_dma<128, 128, 2, 2>(g, (hipStream_t)stream);     // forced 128x128
+            default: return launch_dma<128, 128, 2, 2>(g, (hipStream_t)stream);
+        }
+    }
     return dispatch<0>(g, (hipStream_t)stream);
 }
 
@@ -313,5 +616,6 @@ extern "C" int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout
     g.w = (const uint16_t*)weight; g.bias = bias;
     g.M = B * Hout * Wout; g.N = Cout; g.K = ksize * ksize * Cin;
     g.out = out; g.ldo = out_ld; g.res = (const uint16_t*)res; g.ldres = res_ld; g.flags = flags;
+    g.staged = g_opt_staged && epi_can_stage(g);
     return dispatch<1>(g, (hipStream_t)stream);
 }

@@ -43,6 +43,7 @@ _SIGS = {
     "yv_version": (_i, []),
     "yv_error_string": (C.c_char_p, [_i]),
     "yv_device_is_gfx950": (_i, []),
+    "yv_set_option": (_i, [C.c_char_p, _i]),
     "yv_custom_nms_ws_bytes": (_sz, [_i, _i]),
     "yv_custom_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "yv_efficient_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -87,6 +88,10 @@ def _bind():
 
 
 _bind()
+
+
+def set_option(key: str, value: int):
+    check(lib.yv_set_option(key.encode(), int(value)), "yv_set_option")
 
 
 def check(code: int, what: str = ""):
