@@ -98,10 +98,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     yvhip.LINEAR_HOOK = None
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    from yvhip.dist import max_over_ranks
+    dt = max_over_ranks(dt, dev)
 
     if rank == 0:
         flops = sum(f for f, _, _ in recs)

@@ -96,6 +96,11 @@ int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, size_t img_s
                         const int32_t* crop_total, int cap, int out_size, int patch, int layout, void* out,
                         void* stream);
 
+/* letterbox (YOLOTensorRT_yolodet_py_解读.md:67-69): src (B,Hc,Wc,3) u8 canvas holding image b in its top-left
+ * w x h corner; geom (B,6) i32 rows {w, h, nw, nh, left, top} (host-computed);
+ * out (B,S,S,3) u8: bilinear resample into the window, 114 elsewhere. */
+int yv_letterbox(const uint8_t* src, int B, int Hc, int Wc, const int32_t* geom, int S, uint8_t* out, void* stream);
+
 /* DFL decode + anchors + sigmoid (docs/YOLO_TensorRT_Technical.md:14-30,72-77).
  * Per scale s (3 scales, strides 8/16/32): box logits (B,Hs,Ws,64) f32 and class
  * logits (B,Hs,Ws,cls_ld) f32, NHWC.  Outputs boxes (B,A,4) f32 xyxy input pixels,
@@ -177,9 +182,10 @@ int yv_stem_conv(const uint8_t* images, int B, int H, int W, const float* weight
 /* ------------------------------------------------------------- training */
 
 /* build_loss = LSCE(0.1)/6 + Focal(1,2,'mean')*5/6 (utils/trainClass.py:46-66,162-185,362-370)
+ * loss = w_lsce*LSCE + w_focal*Focal (build_loss: 1/6, 5/6; each term alone: (1,0) / (0,1)).
  * logits (B,nc) f32, labels (B) i32 -> loss (1) f32, grad (B,nc) f32 (d loss / d logits). */
-int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, float* loss, float* grad,
-                    void* stream);
+int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, float w_lsce, float w_focal,
+                    float* loss, float* grad, void* stream);
 
 /* torch.optim.SGD(momentum, weight_decay) step (utils/trainClass.py:442-443), fp32, in place:
  * g += wd*p; m = first ? g : mu*m + g; p -= lr*m. */

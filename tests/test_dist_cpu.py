@@ -1,0 +1,46 @@
+"""world_size-2 gloo test of the N>1 path: shard_range partitions, max-over-ranks timing, ordered gather."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from yvhip.dist import gather_objects, max_over_ranks, shard_range
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 32, 33, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(33, rank, world)
+    local = [f"img{i:03d}" for i in range(lo, hi)]           # each rank "processes" its slice independently
+    t = max_over_ranks(1.0 + rank)                            # slowest rank defines the step time
+    allr = gather_objects(local)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, t, [x for part in allr for x in part]))
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, t, merged in res:
+        assert t == 2.0
+        assert merged == [f"img{i:03d}" for i in range(33)]

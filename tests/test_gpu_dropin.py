@@ -1,0 +1,142 @@
+"""GPU: the reference's call surface end to end (app.py / test.py usage pattern) on the HIP path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle import pipeline as op
+from oracle import train as ot
+from oracle import vit as ov
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class _CFG:
+    num_classes, device, modelName, pretrained = 5, DEV, "vit_tiny_test", None
+
+
+def _make_images(tmp_path, sizes):
+    from PIL import Image
+    g = np.random.default_rng(5)
+    paths = []
+    for i, (w, h) in enumerate(sizes):
+        p = str(tmp_path / f"img_{i}.png")
+        Image.fromarray(g.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    return paths
+
+
+def test_trtmodule_contract():
+    from YOLOTensorRT.models import TRTModule
+    eng = TRTModule("random:n:5:1", torch.device(DEV), size=128)
+    eng.set_desired(['num_dets', 'bboxes', 'scores', 'labels'])
+    H, W = eng.inp_info[0].shape[-2:]
+    assert (H, W) == (128, 128)
+    x = torch.rand(1, 3, 128, 128)
+    x = (x * 255).round() / 255                                  # a blob: u8 / 255
+    num, bb, sc, lb = eng(x.to(DEV))
+    # KAT-2 (test.ipynb:20-24): shapes and dtypes of the 4 engine outputs
+    assert num.shape == (1, 1) and num.dtype == torch.int32
+    assert bb.shape == (1, 100, 4) and bb.dtype == torch.float32
+    assert sc.shape == (1, 100) and sc.dtype == torch.float32 and lb.shape == (1, 100) and lb.dtype == torch.int32
+    n = int(num[0, 0])
+    assert torch.all(sc[0, :n] > 0.25) and float(sc[0, n:].abs().sum()) == 0
+
+
+def test_main_end_to_end(tmp_path):
+    import utils.utils as uu
+    from YOLOTensorRT.inferdet import draw_image, main
+    from YOLOTensorRT.models import TRTModule
+    from yvhip import engines
+    S = 128
+    eng = TRTModule("random:n:5:1", torch.device(DEV), size=S)
+    vsd = engines.init_vit_wrapper_state("vit_tiny_test", 5, seed=2)
+    wpath = str(tmp_path / "best.pth")
+    torch.save(vsd, wpath)
+    model_list = [uu.build_model(CFG=_CFG, modelName="vit_tiny_test", pretrained=wpath)]
+    model_list[-1].to(DEV); model_list[-1].eval()
+    sizes = [(128, 128), (200, 150), (97, 131)]
+    paths = _make_images(tmp_path, sizes)
+    seen = []
+    res = main(Engine=eng, imgs=str(tmp_path), device=torch.device(DEV), model_list=model_list,
+               transform={"valid_test": None}, aliyunoss=None,
+               func=lambda folder, name, path, objs: seen.append((name, len(objs))))
+    import json
+    json.dumps(res)                                               # jsonify-able (app.py:62)
+    assert [r["image"] for r in res["output"]] == sorted(os.path.basename(p) for p in paths)
+    assert sorted(seen) == sorted((r["image"], len(r["objects"])) for r in res["output"])
+    from PIL import Image
+    from YOLOTensorRT.models.utils import letterbox_geometry
+    import yvhip
+    total = 0
+    for r_, p in zip(res["output"], sorted(paths)):
+        img = np.asarray(Image.open(p).convert("RGB"))
+        h, w = img.shape[:2]
+        ratio, dwdh, (nw, nh), (left, top) = letterbox_geometry(h, w, (S, S))
+        # re-run the detector on the device letterbox of this image, then the ORACLE post chain
+        src = torch.from_numpy(img).to(DEV)[None].contiguous()
+        geom = torch.tensor([[w, h, nw, nh, left, top]], dtype=torch.int32, device=DEV)
+        net_in = yvhip.letterbox(src, geom, S)
+        num, bb, sc, lb = [t.cpu() for t in eng(net_in)]
+        dets = op.post_stages(num[0, 0], bb[0], sc[0], lb[0], float(np.float32(ratio)), dwdh, (w, h))
+        dets = [d for d in dets if d["ok"]]
+        assert len(r_["objects"]) == len(dets)
+        for o, d in zip(r_["objects"], dets):
+            assert [o["xmin"], o["ymin"], o["xmax"], o["ymax"]] == d["box"]
+            x = torch.from_numpy(ob.crop_resize_normalize(img, d["rect"]))[None]
+            ref = ov.wrapper_forward(vsd, x, "vit_tiny_test")[0]
+            top2 = ref.topk(2).values
+            if float(top2[0] - top2[1]) > 0.05 * float(ref.abs().max()):
+                from YOLOTensorRT.config import CLASSES
+                assert o["sort"] == CLASSES[int(ref.argmax())]
+            total += 1
+    assert total > 0
+    out = draw_image(image=np.zeros((64, 64, 3), np.uint8), box=[5, 5, 40, 40], cls=1)
+    assert out.shape == (64, 64, 3) and out.any()
+
+
+def test_identity_letterbox_is_exact():
+    import yvhip
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (1, 128, 128, 3), generator=g, dtype=torch.uint8).to(DEV)
+    geom = torch.tensor([[128, 128, 128, 128, 0, 0]], dtype=torch.int32, device=DEV)
+    assert torch.equal(yvhip.letterbox(img, geom, 128), img)
+    # 2x downscale of a constant image stays constant; padding is 114
+    img = torch.full((1, 100, 200, 3), 77, dtype=torch.uint8, device=DEV)
+    geom = torch.tensor([[200, 100, 128, 64, 0, 32]], dtype=torch.int32, device=DEV)
+    out = yvhip.letterbox(img, geom, 128).cpu()
+    assert torch.all(out[0, 32:96] == 77) and torch.all(out[0, :32] == 114) and torch.all(out[0, 96:] == 114)
+
+
+def test_wrapper_module_forward_matches_oracle(tmp_path):
+    import utils.trainClass as tc
+    from yvhip import engines
+    sd = engines.init_vit_wrapper_state("vit_tiny_test", 5, seed=4)
+    p = str(tmp_path / "w.pth"); torch.save(sd, p)
+    net = tc.build_model(_CFG, pretrained=p, modelName="vit_tiny_test").to(DEV).eval()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(3, 3, 224, 224, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    with torch.no_grad():
+        y = net(x.to(DEV))
+    ref = ov.wrapper_forward(sd, x, "vit_tiny_test")
+    assert y.shape == (3, 5) and float((y.cpu() - ref).norm() / ref.norm()) < 2e-2
+    # weights change -> device copies are rebuilt
+    with torch.no_grad():
+        net.fc[3].bias.add_(1.0)
+        y2 = net(x.to(DEV))
+    assert torch.allclose(y2.cpu(), y.cpu() + 1.0, atol=1e-4)
+
+
+def test_losses_autograd(golden):
+    import utils.trainClass as tc
+    for c in golden["G3_loss"]:
+        x = torch.tensor(c["x"], device=DEV, requires_grad=True)
+        y = torch.nn.functional.one_hot(torch.tensor(c["label"]), 5).float().to(DEV)
+        assert abs(float(tc.LabelSmoothingCrossEntropy(0.1)(x, y)) - c["lsce"]) < 3e-6 * max(1, abs(c["lsce"]))
+        assert abs(float(tc.FocalLoss()(x, y)) - c["focal"]) < 3e-6 * max(1, abs(c["focal"]))
+        loss = tc.build_loss(x, y)
+        (loss * 2.0).backward()
+        assert torch.allclose(x.grad.cpu(), 2.0 * torch.tensor(c["grad"]), atol=1e-6, rtol=3e-5)

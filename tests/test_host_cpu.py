@@ -1,0 +1,174 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no compute calls)."""
+import inspect
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+
+
+def test_cfg_matches_reference_attributes(golden):
+    from utils.class_config import CFG
+    ref = golden["CFG"]
+    for k in ref:
+        assert hasattr(CFG, k), k
+    for k in ("seed", "img_size", "train_bs", "valid_bs", "num_classes", "epoch", "lr", "pretrained", "train_path",
+              "valid_path"):
+        assert getattr(CFG, k) == ref[k], k
+    # documented deviation: patch-16 default (BASELINE configs) instead of the reference's patch-8 model
+    assert ref["modelName"] == "vit_base_patch8_224.augreg_in21k" and CFG.modelName.startswith("vit_base_patch16_224")
+
+
+def test_convert_golden(golden):
+    from utils.class_config import convert
+    for c in golden["G8_convert"]:
+        assert list(convert(tuple(c["box"]), *c["wh"])) == c["out"]
+
+
+def test_generate_annotation_golden(golden, tmp_path, capsys):
+    from utils.utils import generate_annotation
+    c = golden["G9_annotation"]
+    out = generate_annotation("image", "a_b.jpg", "/app/image/a_b.jpg", c["objects"], save_dir=str(tmp_path) + "/")
+    assert os.path.basename(out) == c["name"]
+    assert open(out, encoding="utf-8").read() == c["xml"]
+
+
+def test_inflate_box_golden(golden):
+    from utils.trainClass import inflate_box
+    for c in golden["G1_crop_eval"]:
+        x0, y0, x1, y1 = inflate_box(*c["box"], c["W"], c["H"], training=False)
+        if "origin" in c:
+            assert [x0, y0] == c["origin"] and [x1 - x0, y1 - y0] == c["size"]
+    for c in golden["G2_crop_train"]:
+        random.seed(c["seed"])
+        x0, y0, x1, y1 = inflate_box(*c["box"], c["W"], c["H"], training=True)
+        assert [x0, y0] == c["origin"] and [x1 - x0, y1 - y0] == c["size"]
+
+
+def test_crop_image_file(tmp_path):
+    from PIL import Image
+    from inputs import coord_image
+    from utils.trainClass import crop_image
+    p = str(tmp_path / "c.png")
+    Image.fromarray(coord_image(640, 480)).save(p)
+    im = crop_image(p, 100, 50, 300, 250)
+    assert im.size == (220, 220) and np.array(im)[0, 0].tolist()[:2] == [90, 40]
+
+
+def test_schedule_and_correct_golden(golden):
+    from utils.trainClass import cosine_anneal_schedule, getCorrect
+    for E, tab in golden["G4_lr"].items():
+        assert [cosine_anneal_schedule(t, int(E), 1e-4) for t in range(len(tab))] == tab
+    c = golden["G5_correct"]
+    eq, cm = getCorrect(torch.tensor(c["out"]), torch.nn.functional.one_hot(torch.tensor(c["label"]), 5).float())
+    assert eq.int().tolist() == c["eq"] and cm.tolist() == c["cm"]
+
+
+def test_build_model_signatures_and_state_dict(golden, tmp_path):
+    import utils.trainClass as tc
+    import utils.utils as uu
+    from yvhip import engines, modules
+
+    class C:
+        num_classes, device, modelName, pretrained = 5, "cpu", "vit_tiny_test", None
+    sd = engines.init_vit_wrapper_state("vit_tiny_test", 5, seed=3)
+    path = str(tmp_path / "best.pth")
+    torch.save(sd, path)
+    n1 = uu.build_model(CFG=C, modelName="vit_tiny_test", pretrained=path)          # app.py:35 spelling
+    n2 = uu.build_model(C, "vit_tiny_test", pretrained_path=path)                    # utils/utils.py:75 spelling
+    n3 = tc.build_model(C, pretrained=path, modelName="vit_tiny_test")               # utils/trainClass.py:341
+    for n in (n1, n2, n3):
+        got = n.state_dict()
+        assert sorted(got) == sorted(sd)
+        assert all(torch.equal(got[k], sd[k]) for k in sd)
+        assert [k for k in got if not k.startswith("model.")] == golden["G6_keys"]
+    assert list(inspect.signature(tc.build_model).parameters) == ["CFG", "pretrained", "modelName"]
+    # strict loading like the reference: a missing key is an error
+    bad = dict(sd); bad.pop("fc.3.bias")
+    torch.save(bad, path)
+    with pytest.raises(RuntimeError):
+        uu.build_model(C, "vit_tiny_test", path)
+    # timm-layout key census for B/16
+    keys = modules.create_model("vit_base_patch16_224.augreg_in21k").state_dict()
+    assert sum(v.numel() for v in keys.values()) == 86567656
+    with pytest.raises(Exception):
+        modules.create_model("vit_base_patch8_224.augreg_in21k")        # 785 tokens: refused loudly, no fallback
+
+
+def test_star_import_surface():
+    import utils.utils as uu
+    for name in ("build_model", "Network_Wrapper", "download_images", "AliyunOss", "generate_annotation", "location2lalo",
+                 "log", "cv2", "np", "os", "sse", "torch"):
+        assert hasattr(uu, name), name
+    assert hasattr(uu.cv2, "INTER_NEAREST")
+    import utils.trainClass as tc
+    for name in ("buildInferModel", "retrain", "crop_image", "FocalLoss", "LabelSmoothingCrossEntropy", "build_loss",
+                 "cosine_anneal_schedule", "getCorrect", "valid_one_epoch", "train_one_epoch", "build_transforms",
+                 "set_seed", "CFG"):
+        assert hasattr(tc, name), name
+    import utils.trainYolo as ty
+    assert list(inspect.signature(ty.train).parameters) == ["epochs", "batch", "data"] and callable(ty.yoloRetrain)
+
+
+def test_eval_transform_matches_oracle_rule():
+    from utils.trainClass import build_transforms, CFG
+    g = np.random.default_rng(0)
+    img = g.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    out = build_transforms(CFG)["valid_test"](image=img)["image"]
+    exp = ob.crop_resize_normalize(img, (0, 0, 53, 37)).transpose(1, 2, 0)
+    assert out.shape == (224, 224, 3) and np.array_equal(out, exp)
+
+
+def test_yolotensorrt_helpers(tmp_path):
+    from YOLOTensorRT.config import CLASSES
+    from YOLOTensorRT.models import fold_batchnorm
+    from YOLOTensorRT.models.torch_util import det_postprocess
+    from YOLOTensorRT.models.utils import blob, letterbox_geometry, path_to_list
+    assert CLASSES == ['good', 'broke', 'lose', 'uncovered', 'circle']
+    for n in ("b.jpg", "a.png", "c.txt"):
+        (tmp_path / n).write_bytes(b"x")
+    assert [os.path.basename(p) for p in path_to_list(str(tmp_path))] == ["a.png", "b.jpg"]
+    assert path_to_list([str(tmp_path / "b.jpg")]) == [str(tmp_path / "b.jpg")]
+    with pytest.raises(ValueError):
+        path_to_list(str(tmp_path / "c.txt"))
+    r, (dw, dh), (nw, nh), (left, top) = letterbox_geometry(480, 640, (640, 640))
+    assert (r, dw, dh, nw, nh, left, top) == (1.0, 0.0, 80.0, 640, 480, 0, 80)
+    assert letterbox_geometry(1080, 1920)[:3] == ob.letterbox_params(1080, 1920)[:3]
+    x = blob(np.full((4, 6, 3), 255, np.uint8))
+    assert x.shape == (1, 3, 4, 6) and x.dtype == np.float32 and float(x.max()) == 1.0
+    nd = torch.tensor([[2]], dtype=torch.int32)
+    b, s, l = det_postprocess((nd, torch.arange(400.).view(1, 100, 4), torch.ones(1, 100), torch.zeros(1, 100)))
+    assert b.shape == (2, 4) and s.shape == (2,) and l.shape == (2,)
+    # BatchNorm folding == conv followed by BN in eval mode
+    conv = torch.nn.Conv2d(4, 6, 3, bias=False); bn = torch.nn.BatchNorm2d(6, eps=1e-3)
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.normal_(); bn.bias.data.normal_()
+    sd = {"model.1.conv.weight": conv.weight.data, **{"model.1.bn." + k: v for k, v in bn.state_dict().items()}}
+    f = fold_batchnorm(sd)
+    xin = torch.randn(1, 4, 5, 5)
+    ref = bn.eval()(conv(xin))
+    got = torch.nn.functional.conv2d(xin, f["model.1.conv.weight"], f["model.1.conv.bias"])
+    assert torch.allclose(got, ref, atol=1e-5) and not any(".bn." in k for k in f)
+
+
+def test_no_oracle_import_in_product():
+    """The product path must never route through the oracle (or any CPU fallback)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "yolov8-vit_amd")
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f), encoding="utf-8").read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import yvhip
+    with pytest.raises(yvhip.YvError):
+        yvhip.custom_nms(torch.zeros(3, 4), torch.zeros(3))
+    from yvhip import engines
+    with pytest.raises(yvhip.YvError):
+        engines.YoloEngine(engines.init_yolo_state("n", 5), "n", 5, 64)

@@ -81,6 +81,45 @@ __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restr
     }
 }
 
+
+// Letterbox (YOLOTensorRT_yolodet_py_解读.md:67-69): aspect-preserving bilinear resize into the top-left
+// anchored window (left, top, nw, nh) of an S x S canvas filled with 114.  Geometry (ratio, padding) is
+// computed per image on the host in f64 exactly as the published upstream helper does; the kernel only
+// resamples.  Sampling rule: src = (dst + 0.5) * (src_size / dst_size) - 0.5, edge-clamped, f32 blend,
+// round half up (OpenCV's fixed-point INTER_LINEAR is not reproducible without the library: unpinned).
+__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, int Hc, int Wc,
+                                                        const int32_t* __restrict__ geom, int S,
+                                                        uint8_t* __restrict__ out) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= S || y >= S) return;
+    const int32_t* gm = geom + b * 6;                       // w, h, nw, nh, left, top
+    const int w = gm[0], h = gm[1], nw = gm[2], nh = gm[3], left = gm[4], top = gm[5];
+    uint8_t* o = out + (((size_t)b * S + y) * S + x) * 3;
+    const int dx = x - left, dy = y - top;
+    if (dx < 0 || dx >= nw || dy < 0 || dy >= nh) { o[0] = o[1] = o[2] = 114; return; }
+    const uint8_t* im = src + (size_t)b * Hc * Wc * 3;
+    if (nw == w && nh == h) {
+        const uint8_t* p = im + ((size_t)dy * Wc + dx) * 3;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+        return;
+    }
+    float sx = ((float)dx + 0.5f) * ((float)w / (float)nw) - 0.5f;
+    float sy = ((float)dy + 0.5f) * ((float)h / (float)nh) - 0.5f;
+    sx = fminf(fmaxf(sx, 0.f), (float)(w - 1));
+    sy = fminf(fmaxf(sy, 0.f), (float)(h - 1));
+    const int x0 = (int)sx, y0 = (int)sy;
+    const int x1 = x0 + 1 < w ? x0 + 1 : w - 1, y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+    const float fx = sx - (float)x0, fy = sy - (float)y0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = im[((size_t)y0 * Wc + x0) * 3 + c], bq = im[((size_t)y0 * Wc + x1) * 3 + c];
+        const float cq = im[((size_t)y1 * Wc + x0) * 3 + c], d = im[((size_t)y1 * Wc + x1) * 3 + c];
+        const float v = (a + (bq - a) * fx) * (1.f - fy) + (cq + (d - cq) * fx) * fy;
+        o[c] = (uint8_t)fminf(fmaxf(floorf(v + 0.5f), 0.f), 255.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, size_t img_stride,
@@ -106,5 +145,13 @@ extern "C" int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, s
     else
         hipLaunchKernelGGL(crop_kernel<2>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
                            out_size, patch, rows, rcp, out);
+    return yv_launch_status();
+}
+
+extern "C" int yv_letterbox(const uint8_t* src, int B, int Hc, int Wc, const int32_t* geom, int S, uint8_t* out,
+                            void* stream) {
+    if (!src || !geom || !out || B <= 0 || Hc <= 0 || Wc <= 0 || S <= 0) return YV_ERR_ARG;
+    dim3 grid((S + 15) / 16, (S + 15) / 16, B);
+    hipLaunchKernelGGL(letterbox_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, Hc, Wc, geom, S, out);
     return yv_launch_status();
 }

@@ -11,7 +11,8 @@ namespace {
 constexpr int LOSS_MAX_NC = 32;
 
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
-                                                   int B, int nc, float* __restrict__ loss, float* __restrict__ grad) {
+                                                   int B, int nc, float w_ls, float w_fo, float* __restrict__ loss,
+                                                   float* __restrict__ grad) {
     __shared__ float red[4];
     float acc = 0.f;
     const float inv_b = 1.0f / (float)B, inv_bc = 1.0f / ((float)B * (float)nc), inv_c = 1.0f / (float)nc;
@@ -37,9 +38,9 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
             const float sig = 1.f / (1.f + expf(-xc));
             const float g_ls = (p - 0.9f * t - 0.1f * inv_c) * inv_b;
             const float g_fo = (sig - t) * om * (2.f * pt * bce + om) * inv_bc;
-            grad[(size_t)i * nc + c] = g_ls * (1.f / 6.f) + g_fo * (5.f / 6.f);
+            grad[(size_t)i * nc + c] = g_ls * w_ls + g_fo * w_fo;
         }
-        acc += (0.9f * cross + 0.1f * smooth * inv_c) * inv_b * (1.f / 6.f) + fl * inv_bc * (5.f / 6.f);
+        acc += (0.9f * cross + 0.1f * smooth * inv_c) * inv_b * w_ls + fl * inv_bc * w_fo;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -77,11 +78,12 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 
 }  // namespace
 
-extern "C" int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, float* loss, float* grad,
-                               void* stream) {
+extern "C" int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, float w_lsce, float w_focal,
+                               float* loss, float* grad, void* stream) {
     if (!logits || !labels || !loss || !grad || B <= 0 || nc <= 0) return YV_ERR_ARG;
     if (nc > LOSS_MAX_NC) return YV_ERR_LIMIT;
-    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, B, nc, loss, grad);
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, B, nc, w_lsce, w_focal,
+                       loss, grad);
     return yv_launch_status();
 }
 

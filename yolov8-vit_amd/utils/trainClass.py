@@ -1,0 +1,220 @@
+"""Drop-in for the reference's `utils.trainClass` (names, argument meaning and error style).
+
+Hot-path pieces run on the HIP kernels: `build_model`/`Network_Wrapper` (ViT engine), `build_loss` +
+`LabelSmoothingCrossEntropy` + `FocalLoss` (fused loss kernel with its analytic gradient),
+`getCorrect` (device argmax), the eval transform and `crop_image`'s integer inflate.  Dataset walking,
+XML parsing, ONNX export and the augmentation zoo are outside SURVEY.md section 8 and are not rebuilt.
+"""
+import json
+import math
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+from PIL import Image
+
+import yvhip
+from yvhip.modules import Network_Wrapper, build_network  # noqa: F401
+
+from .class_config import *  # noqa: F401,F403  (CFG, like the reference module)
+from .class_config import CFG
+
+
+# ------------------------------------------------------------------------------------------ losses
+class _FusedLoss(torch.autograd.Function):
+    """loss = w_ls*LSCE(0.1) + w_fo*Focal(1,2,'mean'); forward and d/dlogits come from one kernel."""
+
+    @staticmethod
+    def forward(ctx, x, onehot, w_ls, w_fo):
+        yvhip.require_gpu()
+        dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        logits = x.detach().to(dev, torch.float32).contiguous()
+        labels = onehot.detach().to(dev).argmax(1).to(torch.int32).contiguous()
+        loss, grad = yvhip.loss_fwd_bwd(logits, labels, w_ls, w_fo)
+        ctx.save_for_backward(grad)
+        ctx.src = x
+        return loss[0].to(x.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g.to(grad.device)).to(ctx.src.device, ctx.src.dtype), None, None, None
+
+
+class FocalLoss(nn.Module):
+    """utils/trainClass.py:46-66 (alpha 1, gamma 2, reduction 'mean' are the only values the path uses)."""
+
+    def __init__(self, alpha=1, gamma=2, reduction='mean'):
+        super().__init__()
+        if alpha != 1 or gamma != 2 or reduction != 'mean':
+            raise yvhip.YvError("the fused loss kernel implements FocalLoss(alpha=1, gamma=2, reduction='mean')")
+
+    def forward(self, inputs, targets):
+        return _FusedLoss.apply(inputs, targets, 0.0, 1.0)
+
+
+class LabelSmoothingCrossEntropy(nn.Module):
+    """utils/trainClass.py:162-185 with smoothing 0.1 (the value build_loss uses)."""
+
+    def __init__(self, smoothing=0.1):
+        super().__init__()
+        assert 0.0 < smoothing < 1.0
+        if abs(smoothing - 0.1) > 1e-12:
+            raise yvhip.YvError("the fused loss kernel implements smoothing = 0.1")
+        self.smoothing, self.confidence = smoothing, 1.0 - smoothing
+
+    def forward(self, x, targets):
+        return _FusedLoss.apply(x, targets, 1.0, 0.0)
+
+
+def build_loss(x, y):
+    """utils/trainClass.py:362-370: LSCE(0.1)/6 + Focal*5/6 on logits x and one-hot y."""
+    return _FusedLoss.apply(x, y, 1.0 / 6.0, 5.0 / 6.0)
+
+
+# ------------------------------------------------------------------------------- crops / transforms
+def inflate_box(x_min, y_min, x_max, y_max, width, height, training=False):
+    """Integer inflate + clamp of crop_image (utils/trainClass.py:76-91); random draw order
+    x_max, x_min, y_max, y_min in the training branch."""
+    dis_x = (x_max - x_min) // 10
+    dis_y = (y_max - y_min) // 10
+    if training:
+        x_max = min(width, x_max + random.randint(0, dis_x))
+        x_min = max(0, x_min - random.randint(0, dis_x))
+        y_max = min(height, y_max + random.randint(0, dis_y))
+        y_min = max(0, y_min - random.randint(0, dis_y))
+    else:
+        x_max = min(width, x_max + dis_x // 2)
+        x_min = max(0, x_min - dis_x // 2)
+        y_max = min(height, y_max + dis_y // 2)
+        y_min = max(0, y_min - dis_y // 2)
+    return x_min, y_min, x_max, y_max
+
+
+def crop_image(image_path, x_min, y_min, x_max, y_max, training=False):
+    """utils/trainClass.py:70-93: host-side PIL crop (file I/O, outside the device path); the batch
+    pipeline uses the fused crop kernel with the same integer rule."""
+    img = Image.open(image_path).convert('RGB')
+    w, h = img.size
+    return img.crop(inflate_box(x_min, y_min, x_max, y_max, w, h, training))
+
+
+class _EvalTransform:
+    """A.Compose([Resize(h,w,INTER_NEAREST), Normalize(.5,.5)]) as a callable(image=ndarray)->{"image": ...}
+    (utils/trainClass.py:218-221).  Host numpy path for API compatibility; same index/rounding rule as the
+    crop kernel."""
+
+    def __init__(self, size):
+        self.h, self.w = size
+
+    @staticmethod
+    def _idx(dst, src):
+        ifx = 1.0 / (float(dst) / float(src))
+        return np.minimum(np.floor(np.arange(dst) * ifx).astype(np.int64), src - 1)
+
+    def __call__(self, image):
+        a = np.asarray(image)
+        g = a[self._idx(self.h, a.shape[0])][:, self._idx(self.w, a.shape[1])]
+        x = g.astype(np.float32)
+        x -= np.float32(127.5)
+        x *= np.reciprocal(np.float32(127.5), dtype=np.float32)
+        return {"image": x}
+
+
+def build_transforms(CFG):
+    """Only the deterministic `valid_test` branch is on the hot path; the stochastic training
+    augmentations (utils/trainClass.py:199-216) are SURVEY.md 8(f) N4, not built."""
+    t = _EvalTransform(CFG.img_size)
+    return {"train": t, "valid_test": t}
+
+
+# -------------------------------------------------------------------------- schedule / accuracy
+def cosine_anneal_schedule(t, nb_epoch, lr):
+    """utils/trainClass.py:97-105."""
+    cos_inner = np.pi * (t % (nb_epoch))
+    cos_inner /= (nb_epoch)
+    return float(lr / 2 * (np.cos(cos_inner) + 1))
+
+
+def getCorrect(output_concat, target):
+    """utils/trainClass.py:109-117: eq vector (CPU bool tensor) + confusion matrix [true][pred]."""
+    predicted = torch.max(output_concat.data, 1).indices
+    targets = torch.max(target, 1).indices.int()
+    equal = predicted.eq(targets).cpu()
+    n = CFG.num_classes
+    cm = np.bincount((targets.cpu().numpy().astype(np.int64) * n + predicted.cpu().numpy()), minlength=n * n)
+    return equal, cm.reshape(n, n)
+
+
+def set_seed(seed=42):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------- model / eval
+def build_model(CFG, pretrained=None, modelName=None):
+    """utils/trainClass.py:341-358."""
+    return build_network(CFG, modelName, pretrained)
+
+
+def buildInferModel(path="/app/utils/weight/class.onnx"):
+    """The reference opens an onnxruntime session on an exported classifier (utils/trainClass.py:546-554)
+    and returns None on failure.  The native path needs no export: a wrapper state dict at `path` is loaded
+    into the HIP engine; anything else reports the error and returns None."""
+    try:
+        return build_network(CFG, None, path).eval()
+    except Exception as e:
+        print(f"buildInferModel: {e}")
+        return None
+
+
+@torch.no_grad()
+def valid_one_epoch(net, criterion, testloader):
+    """utils/trainClass.py:121-158: mean loss, accuracy in percent, prints the row-normalised confusion matrix."""
+    net.eval()
+    total_cm = np.zeros((CFG.num_classes, CFG.num_classes), dtype=int)
+    test_loss, correct, total, idx = 0.0, 0, 0, 0
+    for batch_idx, (inputs, targets, path) in enumerate(testloader):
+        idx = batch_idx
+        outputs = net(inputs)
+        targets = targets.to(outputs.device).float()
+        test_loss += float(criterion(outputs, targets))
+        eq, cm = getCorrect(outputs.data, targets.data)
+        total_cm += cm
+        total += targets.size(0)
+        correct += int(eq.sum())
+        print('Step: %d | Loss: %.3f |Combined Acc: %.3f%% (%d/%d)' % (
+            batch_idx, test_loss / (batch_idx + 1), 100. * float(correct) / total, correct, total))
+    acc = 100. * float(correct) / max(total, 1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        print(total_cm.astype('float') / total_cm.sum(axis=1)[:, np.newaxis])
+    return acc, test_loss / (idx + 1)
+
+
+# ------------------------------------------------------------------------------------- training
+def train_one_epoch(net, netp, trainloader, CELoss, optimizer, lr, batch_size, epoch, nb_epoch, use_cuda, device):
+    """utils/trainClass.py:374-420.  The fine-tune step (ViT backward + SGD + RCCL all-reduce) is
+    SURVEY.md 8(a) rows C2-C3; its kernels are not part of this round ('what comes next')."""
+    raise yvhip.YvError("ViT backward is not built yet: train_one_epoch is unavailable in this round")
+
+
+def train(CFG, log=False):
+    raise yvhip.YvError("ViT backward is not built yet: train() is unavailable in this round")
+
+
+def retrain(log=False):
+    """app.py:91-94,181-184 call this on a background thread and ignore the return value; the reference
+    style is to report and return instead of raising."""
+    try:
+        set_seed(CFG.seed)
+        train(CFG, log)
+    except Exception as e:
+        print(f"retrain: {e}")
+        return False
+    return True

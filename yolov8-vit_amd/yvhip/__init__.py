@@ -51,6 +51,7 @@ _SIGS = {
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yv_compact_crops": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "yv_crop_resize_norm": (_i, [_vp, _i, _i, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "yv_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "yv_conv2d": (_i, [C.POINTER(yv_view), C.POINTER(yv_view), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
                        _i, _vp]),
@@ -61,7 +62,7 @@ _SIGS = {
     "yv_wrapper_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "yv_sppf_pool": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "yv_stem_conv": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
-    "yv_loss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "yv_loss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "yv_sgd_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _vp]),
 }
 
@@ -217,6 +218,15 @@ def crop_resize_norm(images: torch.Tensor, crop_list: torch.Tensor, crop_total: 
     return out
 
 
+def letterbox(src: torch.Tensor, geom: torch.Tensor, size: int) -> torch.Tensor:
+    """src (B,Hc,Wc,3) u8 canvas, geom (B,6) i32 {w,h,nw,nh,left,top} -> (B,size,size,3) u8."""
+    _chk_dev(src, geom)
+    B, Hc, Wc, _ = src.shape
+    out = torch.empty((B, size, size, 3), dtype=torch.uint8, device=src.device)
+    check(lib.yv_letterbox(_p(src), B, Hc, Wc, _p(geom), size, _p(out), _st()), "yv_letterbox")
+    return out
+
+
 def detect_decode(box_logits, cls_logits, size: int, nc: int):
     """box_logits: 3 x (B,Hs,Ws,64) f32; cls_logits: 3 x (B,Hs,Ws,ld) f32 -> boxes (B,A,4), scores (B,A,nc)."""
     _chk_dev(*box_logits, *cls_logits)
@@ -233,12 +243,13 @@ def detect_decode(box_logits, cls_logits, size: int, nc: int):
 
 
 # --------------------------------------------------------------- training
-def loss_fwd_bwd(logits: torch.Tensor, labels: torch.Tensor):
+def loss_fwd_bwd(logits: torch.Tensor, labels: torch.Tensor, w_lsce: float = 1.0 / 6.0, w_focal: float = 5.0 / 6.0):
     _chk_dev(logits, labels)
     B, nc = logits.shape
     loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
     grad = torch.empty_like(logits)
-    check(lib.yv_loss_fwd_bwd(_p(logits), _p(labels), B, nc, _p(loss), _p(grad), _st()), "yv_loss_fwd_bwd")
+    check(lib.yv_loss_fwd_bwd(_p(logits), _p(labels), B, nc, float(w_lsce), float(w_focal), _p(loss), _p(grad), _st()),
+          "yv_loss_fwd_bwd")
     return loss, grad
 
 

@@ -1,0 +1,41 @@
+"""Multi-GPU plumbing of the inference path: one process per GPU, image batches shard
+embarrassingly, NO data-path collective.  The only exchanges are control-plane scalars (timing max,
+optional result gather) over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in CPU tests)."""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+
+
+def env_rank() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous slice [lo, hi) of n items for `rank`; sizes differ by at most one, earlier ranks larger."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """MAX all-reduce of a host scalar (the bench's elapsed time)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def gather_objects(local: list) -> List[list]:
+    """All ranks' per-image result lists, in rank order (image order is preserved by shard_range)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [local]
+    out: List[list] = [None] * dist.get_world_size()
+    dist.all_gather_object(out, local)
+    return out
