@@ -110,7 +110,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("igemm_linear_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("gemm_dma_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -124,7 +124,7 @@ def main():
                        "weights": "random-init, seed 42"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "igemm_kernel<0,128,128,2,2> (ViT linears)", "launches": n_launch,
+                         "kernel": "gemm_dma_kernel<128,128|256,256> (all ViT linears)", "launches": n_launch,
                          "avg_launch_us": ms * 1e3 / max(n_launch, 1),
                          "alg_flop_per_launch": flops / max(n_launch, 1)},
         }
