@@ -164,9 +164,10 @@ int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, c
 int yv_cls_rows(const float* cls, const float* pos, int R, int tok, int D, float* x, void* stream);
 
 /* Network_Wrapper.fc on backbone logits + argmax (utils/utils.py:64-72, utils/trainClass.py:112):
+ * w1t = fc.1.weight TRANSPOSED, (1000,128) f32 (coalesced rows); w2 = fc.3.weight (nc,128).
  * feats (R, ldf) f32 (first 1000 used) -> logits (R,nc) f32 [accumulated when accumulate!=0,
  * scaled by `scale`: mean-of-logits ensemble over model_list], labels (R) i32 (argmax, first max). */
-int yv_wrapper_head(const float* feats, int ldf, const float* w1, const float* b1, const float* w2, const float* b2,
+int yv_wrapper_head(const float* feats, int ldf, const float* w1t, const float* b1, const float* w2, const float* b2,
                     int R, int nc, float scale, int accumulate, float* logits, int32_t* labels,
                     const int32_t* r_dev, void* stream);
 
@@ -175,7 +176,8 @@ int yv_wrapper_head(const float* feats, int ldf, const float* w1, const float* b
 int yv_sppf_pool(void* buf, int B, int H, int W, int ld, int c, void* stream);
 
 /* Stem: blob (u8 RGB /255, 解读.md:70-74) + Conv 3x3 s2 + bias + SiLU (model.0).
- * images (B,H,W,3) u8; weight (Cout,27) f32 K order (ky,kx,c); out (B,H/2,W/2,Cout) bf16, ld = out_ld. */
+ * images (B,H,W,3) u8; weight (27,Cout) f32, row = (ky*3+kx)*3+c; Cout in {16,32,48};
+ * out (B,H/2,W/2,Cout) bf16, ld = out_ld. */
 int yv_stem_conv(const uint8_t* images, int B, int H, int W, const float* weight, const float* bias, int Cout,
                  void* out, int out_ld, void* stream);
 

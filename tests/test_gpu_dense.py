@@ -182,6 +182,7 @@ def test_wrapper_head_golden(yv, golden_dir):
     fpad = torch.zeros(R, 1024); fpad[:, :1000] = feats
     logits = torch.zeros(R, 5, device=DEV); labels = torch.zeros(R, dtype=torch.int32, device=DEV)
     w = {k: torch.from_numpy(z[k]).to(DEV) for k in ("fc__1__weight", "fc__1__bias", "fc__3__weight", "fc__3__bias")}
+    w["fc__1__weight"] = w["fc__1__weight"].t().contiguous()          # the kernel takes fc.1.weight transposed
     yv.wrapper_head(fpad.to(DEV), w["fc__1__weight"], w["fc__1__bias"], w["fc__3__weight"], w["fc__3__bias"], R, 5,
                     logits, labels)
     assert torch.allclose(logits.cpu(), exp, atol=1e-5, rtol=1e-5)          # f32, summation order only
@@ -215,5 +216,5 @@ def test_stem_conv(yv):
     w = torch.randn(16, 3, 3, 3, generator=g) * 0.3; b = torch.randn(16, generator=g) * 0.1
     ref = F.silu(F.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, w, b, stride=2, padding=1))
     out = torch.zeros(B, H // 2, H // 2, 16, dtype=torch.bfloat16, device=DEV)
-    yv.stem_conv(img.to(DEV), w.permute(0, 2, 3, 1).reshape(16, 27).contiguous().to(DEV), b.to(DEV), out)
+    yv.stem_conv(img.to(DEV), w.permute(2, 3, 1, 0).reshape(27, 16).contiguous().to(DEV), b.to(DEV), out)
     assert rel_l2(out.permute(0, 3, 1, 2).float().cpu(), ref) < 3e-3

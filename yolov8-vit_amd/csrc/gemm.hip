@@ -58,19 +58,18 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// exact-erf GELU; erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output step)
+// exact-erf GELU; erfc by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output step):
+//   w = 0.5*erfc(|x|/sqrt2) = t*(a1+t*(a2+...))*exp(-x^2/2),  t = 1/(1+p|x|/sqrt2)   (0.5 folded into a_i)
+//   gelu(x) = x*Phi(x) = max(x,0) - |x*w|
 __device__ __forceinline__ float gelu_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-z * z);          // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);     // exp(-x^2/2)
+    return fmaxf(x, 0.0f) - fabsf(x * (p * t * e));
 }
-
-
 template <int MF, int NF>
 __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[NF][MF], int M, int m0, int n0, int wrow_m,
                                          int wrow_n, int fr, int fq) {

@@ -69,26 +69,35 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
 constexpr int WH_FEAT = 1000, WH_HID = 128, WH_MAX_NC = 32;
 
 __global__ __launch_bounds__(256) void wrapper_head_kernel(const float* __restrict__ feats, int ldf,
-                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w1t, const float* __restrict__ b1,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
                                                            int nc, float scale, int accumulate,
                                                            float* __restrict__ logits, int32_t* __restrict__ labels,
                                                            const int32_t* __restrict__ r_dev) {
+    // w1t is fc.1.weight TRANSPOSED: (1000, 128), so the 128 hidden units of one k are one coalesced 512-B row
     __shared__ float f[WH_FEAT];
+    __shared__ float part[2][WH_HID];
     __shared__ float h[WH_HID];
     __shared__ float lg[WH_MAX_NC];
     const int r = blockIdx.x;
     if (r_dev && r >= r_dev[0]) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     for (int i = tid; i < WH_FEAT; i += 256) f[i] = fmaxf(feats[(size_t)r * ldf + i], 0.f);     // ReLU
     __syncthreads();
-    for (int u = wave * 32; u < wave * 32 + 32; ++u) {
-        const float* wr = w1 + (size_t)u * WH_FEAT;
-        float s = 0.f;
-        for (int k = lane; k < WH_FEAT; k += 64) s = fmaf(f[k], wr[k], s);
-        s = wave_sum(s);
-        if (lane == 0) h[u] = fmaxf(s + b1[u], 0.f);                                             // ReLU
+    {
+        const int u = tid & (WH_HID - 1), half = tid >> 7;                    // 2 K-halves x 128 units
+        const int k0 = half * (WH_FEAT / 2);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int k = k0; k < k0 + WH_FEAT / 2; k += 4) {
+            s0 = fmaf(f[k], w1t[(size_t)k * WH_HID + u], s0);
+            s1 = fmaf(f[k + 1], w1t[(size_t)(k + 1) * WH_HID + u], s1);
+            s2 = fmaf(f[k + 2], w1t[(size_t)(k + 2) * WH_HID + u], s2);
+            s3 = fmaf(f[k + 3], w1t[(size_t)(k + 3) * WH_HID + u], s3);
+        }
+        part[half][u] = (s0 + s1) + (s2 + s3);
     }
+    __syncthreads();
+    if (tid < WH_HID) h[tid] = fmaxf(part[0][tid] + part[1][tid] + b1[tid], 0.f);               // ReLU
     __syncthreads();
     if (tid < nc) {
         const float* wr = w2 + (size_t)tid * WH_HID;
@@ -131,13 +140,13 @@ extern "C" int yv_cls_rows(const float* cls, const float* pos, int R, int tok, i
     return yv_launch_status();
 }
 
-extern "C" int yv_wrapper_head(const float* feats, int ldf, const float* w1, const float* b1, const float* w2,
+extern "C" int yv_wrapper_head(const float* feats, int ldf, const float* w1t, const float* b1, const float* w2,
                                const float* b2, int R, int nc, float scale, int accumulate, float* logits,
                                int32_t* labels, const int32_t* r_dev, void* stream) {
-    if (!feats || !w1 || !b1 || !w2 || !b2 || !logits || !labels || R < 0 || ldf < WH_FEAT) return YV_ERR_ARG;
+    if (!feats || !w1t || !b1 || !w2 || !b2 || !logits || !labels || R < 0 || ldf < WH_FEAT) return YV_ERR_ARG;
     if (nc <= 0 || nc > WH_MAX_NC) return YV_ERR_LIMIT;
     if (R == 0) return YV_OK;
-    hipLaunchKernelGGL(wrapper_head_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, feats, ldf, w1, b1, w2, b2, nc,
+    hipLaunchKernelGGL(wrapper_head_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, feats, ldf, w1t, b1, w2, b2, nc,
                        scale, accumulate, logits, labels, r_dev);
     return yv_launch_status();
 }

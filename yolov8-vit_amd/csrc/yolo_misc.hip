@@ -9,19 +9,12 @@
 
 namespace {
 
-constexpr int STEM_MAX_C = 64;
-
+template <int COUT>
 __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ img, int H, int W,
                                                    const float* __restrict__ wgt, const float* __restrict__ bias,
-                                                   int Cout, uint16_t* __restrict__ out, int out_ld, long long npix) {
-    __shared__ float ws[27 * STEM_MAX_C];       // [tap*3+c][cout]
-    __shared__ float bs[STEM_MAX_C];
-    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
-        const int k = i / Cout, co = i - k * Cout;
-        ws[i] = wgt[co * 27 + k];
-    }
-    for (int i = threadIdx.x; i < Cout; i += 256) bs[i] = bias[i];
-    __syncthreads();
+                                                   uint16_t* __restrict__ out, int out_ld, long long npix) {
+    // weights are indexed with compile-time constants only -> the compiler keeps them on the scalar path
+    // (s_load + SGPR operands): no LDS, no per-lane weight traffic.  wgt layout here: [tap*3+c][COUT].
     const int Ho = H >> 1, Wo = W >> 1;
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= npix) return;
@@ -41,18 +34,15 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ i
             for (int c = 0; c < 3; ++c) x[(ky * 3 + kx) * 3 + c] = ok ? (float)px[c] / 255.0f : 0.f;
         }
     uint16_t* o = out + p * out_ld;
-    for (int cg = 0; cg < Cout; cg += 8) {
+#pragma unroll
+    for (int cg = 0; cg < COUT; cg += 8) {
         float acc[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = bs[cg + q];
+        for (int q = 0; q < 8; ++q) acc[q] = bias[cg + q];
 #pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            const float4 w0 = *(const float4*)(ws + k * Cout + cg), w1 = *(const float4*)(ws + k * Cout + cg + 4);
-            acc[0] = fmaf(x[k], w0.x, acc[0]); acc[1] = fmaf(x[k], w0.y, acc[1]);
-            acc[2] = fmaf(x[k], w0.z, acc[2]); acc[3] = fmaf(x[k], w0.w, acc[3]);
-            acc[4] = fmaf(x[k], w1.x, acc[4]); acc[5] = fmaf(x[k], w1.y, acc[5]);
-            acc[6] = fmaf(x[k], w1.z, acc[6]); acc[7] = fmaf(x[k], w1.w, acc[7]);
-        }
+        for (int k = 0; k < 27; ++k)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = fmaf(x[k], wgt[k * COUT + cg + q], acc[q]);
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = acc[q] / (1.0f + __expf(-acc[q]));      // SiLU
         *(uint4*)(o + cg) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
@@ -73,36 +63,40 @@ __device__ __forceinline__ uint4 pack8(const float* m) {
                       pack_bf16x2(m[6], m[7]));
 }
 
-__global__ __launch_bounds__(256) void sppf_kernel(uint16_t* __restrict__ buf, int H, int W, int ld, int c,
-                                                   long long items) {
-    const long long it = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (it >= items) return;
+// one workgroup per (image, 8-channel group): the H x W plane of 16-byte vectors sits in LDS and the three
+// MaxPool2d(5,1,2) are chained exactly like the reference module (75 LDS reads per pixel instead of 169 global)
+constexpr int SPPF_MAX_HW = 1600;          // 40 x 40 (P5 of a 1280 input)
+__global__ __launch_bounds__(512) void sppf_kernel(uint16_t* __restrict__ buf, int H, int W, int ld, int c) {
+    __shared__ uint4 plane[2][SPPF_MAX_HW];
     const int cgs = c >> 3;
-    const int cg = (int)(it % cgs);
-    const long long pix = it / cgs;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const long long b = pix / ((long long)W * H);
-    float m5[8], m9[8], m13[8];
+    const int b = blockIdx.x / cgs, cg = blockIdx.x - b * cgs;
+    const int hw = H * W;
+    uint16_t* base = buf + (size_t)b * hw * ld + cg * 8;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) plane[0][i] = *(const uint4*)(base + (size_t)i * ld);
+    __syncthreads();
+    for (int stage = 0; stage < 3; ++stage) {
+        const uint4* in = plane[stage & 1];
+        uint4* outp = plane[(stage + 1) & 1];
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+            const int y = i / W, x = i - y * W;
+            float m[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) m5[q] = m9[q] = m13[q] = -INFINITY;
-    for (int dy = -6; dy <= 6; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        for (int dx = -6; dx <= 6; ++dx) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= W) continue;
-            const uint4 v = *(const uint4*)(buf + ((b * H + yy) * W + xx) * ld + cg * 8);
-            const int r = max(abs(dy), abs(dx));
-            max8(m13, v);
-            if (r <= 4) max8(m9, v);
-            if (r <= 2) max8(m5, v);
+            for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= W) continue;
+                    max8(m, in[yy * W + xx]);
+                }
+            }
+            const uint4 v = pack8(m);
+            outp[i] = v;
+            *(uint4*)(base + (size_t)i * ld + (stage + 1) * c) = v;
         }
+        __syncthreads();
     }
-    uint16_t* o = buf + ((b * H + y) * W + x) * ld + cg * 8;
-    *(uint4*)(o + c) = pack8(m5);
-    *(uint4*)(o + 2 * c) = pack8(m9);
-    *(uint4*)(o + 3 * c) = pack8(m13);
 }
 
 }  // namespace
@@ -110,19 +104,22 @@ __global__ __launch_bounds__(256) void sppf_kernel(uint16_t* __restrict__ buf, i
 extern "C" int yv_stem_conv(const uint8_t* images, int B, int H, int W, const float* weight, const float* bias,
                             int Cout, void* out, int out_ld, void* stream) {
     if (!images || !weight || !bias || !out || B <= 0 || H <= 0 || W <= 0) return YV_ERR_ARG;
-    if ((H & 1) || (W & 1) || (Cout & 7) || Cout <= 0 || (out_ld & 7) || out_ld < Cout) return YV_ERR_ARG;
-    if (Cout > STEM_MAX_C) return YV_ERR_LIMIT;
+    if ((H & 1) || (W & 1) || (out_ld & 7) || out_ld < Cout) return YV_ERR_ARG;
+    if (Cout != 16 && Cout != 32 && Cout != 48) return YV_ERR_LIMIT;             // YOLOv8 n / s / m stems
     const long long npix = (long long)B * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images, H,
-                       W, weight, bias, Cout, (uint16_t*)out, out_ld, npix);
+    const dim3 grid((unsigned)((npix + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t* o = (uint16_t*)out;
+    if (Cout == 16) hipLaunchKernelGGL(stem_kernel<16>, grid, block, 0, st, images, H, W, weight, bias, o, out_ld, npix);
+    else if (Cout == 32) hipLaunchKernelGGL(stem_kernel<32>, grid, block, 0, st, images, H, W, weight, bias, o, out_ld, npix);
+    else hipLaunchKernelGGL(stem_kernel<48>, grid, block, 0, st, images, H, W, weight, bias, o, out_ld, npix);
     return yv_launch_status();
 }
 
 extern "C" int yv_sppf_pool(void* buf, int B, int H, int W, int ld, int c, void* stream) {
     if (!buf || B <= 0 || H <= 0 || W <= 0 || c <= 0) return YV_ERR_ARG;
     if ((c & 7) || (ld & 7) || ld < 4 * c) return YV_ERR_ARG;
-    const long long items = (long long)B * H * W * (c / 8);
-    hipLaunchKernelGGL(sppf_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (uint16_t*)buf, H, W, ld, c, items);
+    if (H * W > SPPF_MAX_HW) return YV_ERR_LIMIT;
+    hipLaunchKernelGGL(sppf_kernel, dim3(B * (c / 8)), dim3(512), 0, (hipStream_t)stream, (uint16_t*)buf, H, W, ld, c);
     return yv_launch_status();
 }

@@ -341,5 +341,5 @@ def sppf_pool(buf: torch.Tensor, c: int):
 
 def stem_conv(images: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out: torch.Tensor):
     B, H, W, _ = images.shape
-    check(lib.yv_stem_conv(_p(images), B, H, W, _p(weight), _p(bias), weight.shape[0], _p(out), out.shape[-1],
+    check(lib.yv_stem_conv(_p(images), B, H, W, _p(weight), _p(bias), weight.shape[1], _p(out), out.shape[-1],
                            _st()), "yv_stem_conv")

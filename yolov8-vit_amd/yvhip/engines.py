@@ -130,7 +130,7 @@ class YoloEngine:
             if tuple(wt.shape) != (co, ci, k, k):
                 raise YvError(f"{key}.weight has shape {tuple(wt.shape)}, expected {(co, ci, k, k)}")
             if key == "model.0.conv":
-                self.w[key] = wt.float().permute(0, 2, 3, 1).reshape(co, 27).contiguous().to(self.dev)
+                self.w[key] = wt.float().permute(2, 3, 1, 0).reshape(27, co).contiguous().to(self.dev)    # (tap*3+c, cout)
             else:
                 self.w[key] = _khwc(wt.float()).to(self.dev)
             self.b[key] = bs.float().contiguous().to(self.dev)
@@ -336,7 +336,7 @@ class VitEngine:
         bh = torch.zeros(1024)
         bh[:1000] = g("head.bias").float()
         self.w_head, self.b_head = bf(wh), f32(bh)
-        self.fc1w, self.fc1b = f32(state["fc.1.weight"]), f32(state["fc.1.bias"])
+        self.fc1w, self.fc1b = f32(state["fc.1.weight"].float().t()), f32(state["fc.1.bias"])     # (1000,128): transposed
         self.fc2w, self.fc2b = f32(state["fc.3.weight"]), f32(state["fc.3.bias"])
         if tuple(self.fc2w.shape) != (num_classes, 128):
             raise YvError("fc.3.weight does not match num_classes")
