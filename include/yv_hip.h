@@ -157,7 +157,8 @@ int yv_layernorm(const float* x, size_t ldx, const float* gamma, const float* be
 
 /* Fused attention forward, non-causal: softmax(Q K^T * scale) V (timm Attention; README.md:21-23).
  * qkv (R*N, 3*H*64) bf16 as produced by the qkv Linear ([q|k|v], head-major);
- * out (R*N, H*64) bf16.  head dim 64; N <= 256 per pass (ViT-x/16: 197). */
+ * out (R*N, H*64) bf16.  head dim 64; N <= 256 is one K/V tile (ViT-x/16: 197), longer sequences
+ * (ViT-B/8: 785) are tiled with an online softmax. */
 int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev, void* stream);
 
 /* cls rows of the token stream: x[r*(tok+1), :] = cls + pos[0]  (timm cls_token + pos_embed) */

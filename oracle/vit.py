@@ -21,6 +21,7 @@ VIT_CFGS = {
     "vit_base_patch8_224": (8, 768, 12, 12),
     "vit_large_patch16_224": (16, 1024, 24, 16),
     "vit_tiny_test": (16, 128, 2, 2),          # test-only miniature (d = 64)
+    "vit_tiny8_test": (8, 128, 2, 2),          # test-only miniature with 785 tokens
 }
 
 

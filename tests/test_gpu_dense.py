@@ -145,7 +145,8 @@ def test_layernorm(yv):
     assert rel_l2(y.cpu().float()[:4], ref[:4]) < 3e-3 and float(y[4:].float().abs().sum()) == 0
 
 
-@pytest.mark.parametrize("R,N,H", [(3, 197, 12), (2, 5, 2), (2, 50, 2), (1, 256, 3), (2, 33, 1), (1, 64, 2)])
+@pytest.mark.parametrize("R,N,H", [(3, 197, 12), (2, 5, 2), (2, 50, 2), (1, 256, 3), (2, 33, 1), (1, 64, 2),
+                                   (2, 785, 3), (1, 257, 2), (1, 512, 1), (1, 1000, 2)])
 def test_attention(yv, R, N, H):
     g = torch.Generator().manual_seed(R * 7 + N)
     D = H * 64

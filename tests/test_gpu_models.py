@@ -16,7 +16,8 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-@pytest.mark.parametrize("name,R", [("vit_tiny_test", 3), ("vit_base_patch16_224", 2)])
+@pytest.mark.parametrize("name,R", [("vit_tiny_test", 3), ("vit_base_patch16_224", 2), ("vit_tiny8_test", 2),
+                                    ("vit_base_patch8_224", 1)])
 def test_vit_engine_vs_oracle(name, R):
     from yvhip import engines
     sd = ov.init_wrapper_state(name, seed=11)

@@ -15,11 +15,9 @@ def test_cfg_matches_reference_attributes(golden):
     ref = golden["CFG"]
     for k in ref:
         assert hasattr(CFG, k), k
-    for k in ("seed", "img_size", "train_bs", "valid_bs", "num_classes", "epoch", "lr", "pretrained", "train_path",
-              "valid_path"):
+    for k in ("seed", "img_size", "train_bs", "valid_bs", "num_classes", "epoch", "lr", "modelName", "pretrained",
+              "train_path", "valid_path"):
         assert getattr(CFG, k) == ref[k], k
-    # documented deviation: patch-16 default (BASELINE configs) instead of the reference's patch-8 model
-    assert ref["modelName"] == "vit_base_patch8_224.augreg_in21k" and CFG.modelName.startswith("vit_base_patch16_224")
 
 
 def test_convert_golden(golden):
@@ -94,8 +92,10 @@ def test_build_model_signatures_and_state_dict(golden, tmp_path):
     # timm-layout key census for B/16
     keys = modules.create_model("vit_base_patch16_224.augreg_in21k").state_dict()
     assert sum(v.numel() for v in keys.values()) == 86567656
+    k8 = modules.create_model("vit_base_patch8_224.augreg_in21k").state_dict()   # the reference's configured model
+    assert k8["pos_embed"].shape == (1, 785, 768) and k8["patch_embed.proj.weight"].shape == (768, 3, 8, 8)
     with pytest.raises(Exception):
-        modules.create_model("vit_base_patch8_224.augreg_in21k")        # 785 tokens: refused loudly, no fallback
+        modules.create_model("resnet50")                                 # unknown backbone: refused loudly
 
 
 def test_star_import_surface():

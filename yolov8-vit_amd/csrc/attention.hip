@@ -1,9 +1,10 @@
-// Fused non-causal attention forward for ViT token counts (N <= 256, head dim 64):
+// Fused non-causal attention forward for ViT token counts (197 single-tile, 785 tiled), head dim 64:
 //   O = softmax(Q K^T * scale) V              timm Attention (README.md:21-23), SURVEY.md row B3 / K10.
 //
-// One workgroup per (crop, head); wave w owns query rows [32w, 32w+32).  K (row major)
-// and V^T live whole in LDS (N = 197: 28 KB + 29 KB), so there is no online-softmax
-// rescale: each wave computes its full 32 x N score block in registers.
+// One workgroup per (crop, head, query block); wave w owns 32 query rows.  K (row major) and V^T tiles
+// live in LDS; at N = 197 the whole sequence is ONE tile (28 KB + 29 KB) so there is no online-softmax
+// rescale and each wave computes its full 32 x N score block in registers; longer sequences (ViT-B/8:
+// 785 tokens) walk 256-row K/V tiles with running max / sum.
 //
 // MFMA plan (v_mfma_f32_32x32x16_bf16, accumulators in f32):
 //   S^T tile = K_tile (A: 32 keys x 64 d) . Q^T (B: 64 d x 32 queries)
@@ -24,115 +25,136 @@ namespace {
 constexpr int HD = 64;
 
 template <int NT>
-__global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __restrict__ qkv, int N, int H,
+__global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __restrict__ qkv, int N, int H, int QB,
                                                             float scale_log2e, uint16_t* __restrict__ out,
                                                             const int32_t* __restrict__ r_dev) {
+    // blockIdx.x = ((crop * H + head) * QB + query block); a query block = NT waves x 32 queries = NP rows.
+    // Keys/values are consumed in tiles of NP rows with an online softmax (running max m, sum l, rescaled
+    // O); N <= NP (ViT-x/16: 197 <= 224) is the single-tile case and pays no rescale.
     constexpr int NP = NT * 32;
     constexpr int VT_STRIDE = NP * 2 + 8;               // bytes per V^T row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;                            // NP x 128 B
     unsigned char* Vt = smem + NP * 128;                 // 64 x VT_STRIDE
-    const int r = blockIdx.x / H, hd = blockIdx.x - r * H;
+    const int qb = blockIdx.x % QB;
+    const int rh = blockIdx.x / QB;
+    const int r = rh / H, hd = rh - r * H;
     if (r_dev && r >= r_dev[0]) return;
     const int D = H * HD, ld = 3 * D;
     const uint16_t* base = qkv + (size_t)r * N * ld + hd * HD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int T = NT * 64;
 
-    // ---- stage K (swizzled rows) and V^T (explicit transpose) -----------------------------
-    for (int it = tid; it < NP * 8; it += T) {
-        const int key = it >> 3, c = it & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < N) {
-            kv = *(const uint4*)(base + (size_t)key * ld + D + c * 8);
-            vv = *(const uint4*)(base + (size_t)key * ld + 2 * D + c * 8);
-        }
-        *(uint4*)(Ks + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = kv;
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint16_t val = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
-            *(uint16_t*)(Vt + (c * 8 + e) * VT_STRIDE + key * 2) = val;
-        }
-    }
-
     // ---- Q fragments (B operand), straight from global --------------------------------------
     const int rl = lane & 31, hh = lane >> 5;
-    const int q = wave * 32 + rl;
+    const int q = qb * NP + wave * 32 + rl;
     const int qc = q < N ? q : N - 1;
     bf16x8 fq[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fq[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
-    __syncthreads();
 
-    // ---- S^T = K . Q^T ------------------------------------------------------------------------
-    f32x16 s[NT];
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
-        const int row = kt * 32 + rl;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = 2 * ks + hh;
-            const bf16x8 fk = *(const bf16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], s[kt], 0, 0, 0);
-        }
-    }
-
-    // ---- softmax over keys (register axis + lane^32) -----------------------------------------
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            const float v = key < N ? s[kt][e] : -INFINITY;
-            s[kt][e] = v;
-            mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mb = mx * scale_log2e;
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float p = exp2f(s[kt][e] * scale_log2e - mb);
-            s[kt][e] = p;
-            l += p;
-        }
-    l += __shfl_xor(l, 32, 64);
-
-    // ---- O^T = V^T . P^T ------------------------------------------------------------------------
     f32x16 o[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kv0 = 0; kv0 < N; kv0 += NP) {
+        if (kv0 > 0) __syncthreads();                    // every wave is done reading the previous tile
+        // ---- stage K (swizzled rows) and V^T (explicit transpose) -------------------------
+        for (int it = tid; it < NP * 8; it += T) {
+            const int kl = it >> 3, c = it & 7;
+            const int key = kv0 + kl;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (key < N) {
+                kv = *(const uint4*)(base + (size_t)key * ld + D + c * 8);
+                vv = *(const uint4*)(base + (size_t)key * ld + 2 * D + c * 8);
+            }
+            *(uint4*)(Ks + kl * 128 + ((c ^ ((kl >> 1) & 7)) << 4)) = kv;
+            const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
+            for (int e = 0; e < 8; ++e) {
+                const uint16_t val = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+                *(uint16_t*)(Vt + (c * 8 + e) * VT_STRIDE + kl * 2) = val;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T ------------------------------------------------------------------
+        f32x16 s[NT];
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            bf16x8 fp;
+        for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fp[j] = (__bf16)s[kt][8 * st + j];
-            const int key0 = kt * 32 + 16 * st + 4 * hh;
+            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+            const int row = kt * 32 + rl;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const unsigned char* vr = Vt + (mt * 32 + rl) * VT_STRIDE + key0 * 2;
-                const uint2 lo = *(const uint2*)vr;
-                const uint2 hi = *(const uint2*)(vr + 16);
-                const u32x4 pk = {lo.x, lo.y, hi.x, hi.y};
-                const bf16x8 fv = __builtin_bit_cast(bf16x8, pk);
-                o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fp, o[mt], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 2 * ks + hh;
+                const bf16x8 fk = *(const bf16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], s[kt], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax over this tile's keys (register axis + lane^32) -----------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kv0 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const float v = key < N ? s[kt][e] : -INFINITY;
+                s[kt][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);            // every tile holds >= 1 valid key -> finite
+        const float alpha = exp2f((m_run - m_new) * scale_log2e);   // first tile: exp2(-inf) = 0
+        const float mb = m_new * scale_log2e;
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = exp2f(s[kt][e] * scale_log2e - mb);
+                s[kt][e] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 32, 64);
+        l_run = l_run * alpha + l;
+        m_run = m_new;
+        if (kv0 > 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
+        }
+
+        // ---- O^T += V^T . P^T ---------------------------------------------------------------
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 fp;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fp[j] = (__bf16)s[kt][8 * st + j];
+                const int key0 = kt * 32 + 16 * st + 4 * hh;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const unsigned char* vr = Vt + (mt * 32 + rl) * VT_STRIDE + key0 * 2;
+                    const uint2 lo = *(const uint2*)vr;
+                    const uint2 hi = *(const uint2*)(vr + 16);
+                    const u32x4 pk = {lo.x, lo.y, hi.x, hi.y};
+                    const bf16x8 fv = __builtin_bit_cast(bf16x8, pk);
+                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fp, o[mt], 0, 0, 0);
+                }
             }
         }
     }
 
     // ---- normalise and store: lane owns d = 32mt + 8g + 4hh .. +3 of its query -------------
     if (q < N) {
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / l_run;
         uint16_t* orow = out + ((size_t)r * N + q) * D + hd * HD;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -154,7 +176,9 @@ int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t*
     if (lds > 65536 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(R * H), dim3(NT * 64), lds, st, qkv, N, H, scale * 1.4426950408889634f, out, r_dev);
+    const int QB = (N + NP - 1) / NP;
+    hipLaunchKernelGGL(kern, dim3(R * H * QB), dim3(NT * 64), lds, st, qkv, N, H, QB, scale * 1.4426950408889634f, out,
+                       r_dev);
     return yv_launch_status();
 }
 
@@ -163,12 +187,12 @@ int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t*
 extern "C" int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev,
                             void* stream) {
     if (!qkv || !out || R < 0 || N <= 0 || H <= 0) return YV_ERR_ARG;
-    if (N > 256) return YV_ERR_LIMIT;
+    if ((long long)R * H * ((N + 255) / 256) > 0x7fffffffLL) return YV_ERR_LIMIT;
     if (R == 0) return YV_OK;
     const uint16_t* q = (const uint16_t*)qkv;
     uint16_t* o = (uint16_t*)out;
     hipStream_t st = (hipStream_t)stream;
-    const int nt = (N + 31) / 32;
+    const int nt = N > 256 ? 8 : (N + 31) / 32;        // > 256 tokens: 256-row tiles, online softmax
     switch (nt) {
         case 1: return launch_attn<1>(q, R, N, H, scale, o, r_dev, st);
         case 2: return launch_attn<2>(q, R, N, H, scale, o, r_dev, st);

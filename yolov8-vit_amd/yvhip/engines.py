@@ -261,16 +261,17 @@ class YoloEngine:
 # ------------------------------------------------------------------------------------------ ViT
 VIT_CFGS = {
     "vit_base_patch16_224": (16, 768, 12, 12),
+    "vit_base_patch8_224": (8, 768, 12, 12),            # the reference's configured model (utils/class_config.py:21)
     "vit_large_patch16_224": (16, 1024, 24, 16),
     "vit_tiny_test": (16, 128, 2, 2),
+    "vit_tiny8_test": (8, 128, 2, 2),
 }
 
 
 def vit_cfg(name: str):
     base = name.split(".")[0]
     if base not in VIT_CFGS:
-        raise YvError(f"classifier '{name}' is not supported by the MI355X path "
-                      f"(supported: {sorted(VIT_CFGS)}; patch-8 / 785-token models need the tiled attention kernel)")
+        raise YvError(f"classifier '{name}' is not supported by the MI355X path (supported: {sorted(VIT_CFGS)})")
     return VIT_CFGS[base]
 
 
@@ -310,8 +311,6 @@ class VitEngine:
         self.name, self.nc, self.img, self.dev = name, num_classes, img, torch.device(device)
         self.tok = (img // self.P) ** 2
         self.N = self.tok + 1
-        if self.N > 256:
-            raise YvError("token count > 256 needs the tiled attention kernel")
         dev, D = self.dev, self.D
         bf = lambda t: t.float().contiguous().to(torch.bfloat16).to(dev)
         f32 = lambda t: t.float().contiguous().to(dev)
