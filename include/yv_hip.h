@@ -128,6 +128,8 @@ typedef struct yv_view {
 #define YV_EPI_RES_BF16 16  /* + bf16 residual view (Bottleneck shortcut)     */
 #define YV_EPI_OUT_F32 32   /* store f32 instead of bf16                      */
 #define YV_EPI_POSEMB 64    /* patch-embed row remap + pos_embed add          */
+#define YV_EPI_SAVE_PRE 128 /* also store the pre-activation (bf16) to `aux`   */
+#define YV_EPI_GELU_BWD 256 /* out = acc * gelu'(aux)  (MLP backward)         */
 
 /* Conv2d(k in {1,3}, stride in {1,2}, pad k/2) + folded-BN bias + SiLU as an
  * implicit GEMM on MFMA (ultralytics Conv/C2f/SPPF/Detect convs; structure per
@@ -148,6 +150,12 @@ int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout,
  * YV_EPI_POSEMB: row m -> out row (m/tok)*(tok+1)+1+(m%tok), adds pos[(1+m%tok)*N + n]. */
 int yv_linear(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out, int ldo,
               const float* pos, int tok, int flags, const int32_t* m_dev, int m_mul, void* stream);
+
+/* Training form of yv_linear: res_f32 = separate f32 residual source (out = res_f32 + acc + bias, so the
+ * residual stream of every layer can be kept for backward); aux/ldaux = bf16 side buffer for
+ * YV_EPI_SAVE_PRE / YV_EPI_GELU_BWD.  Requires K % 64 == 0, N > 64 and 16-byte aligned rows. */
+int yv_linear_ex(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out, int ldo,
+                 int flags, const float* res_f32, void* aux, int ldaux, void* stream);
 
 /* LayerNorm over the last dim (timm blocks.*.norm1/2, norm; eps 1e-6; README.md:21-29).
  * x (rows, D) f32 with row stride ldx -> y (rows, D) bf16 row stride ldy.
@@ -183,6 +191,43 @@ int yv_stem_conv(const uint8_t* images, int B, int H, int W, const float* weight
                  void* out, int out_ld, void* stream);
 
 /* ------------------------------------------------------------- training */
+
+/* Forward attention that also returns the per-(crop, head, query) log2-sum-exp for the backward pass. */
+int yv_attention_train(const void* qkv, int R, int N, int H, float scale, void* out, float* lse, void* stream);
+
+/* Attention backward (timm Attention, README.md:21-23; N <= 256): qkv/out/dout as in the forward, lse from
+ * yv_attention_train; writes dqkv (R*N, 3*H*64) bf16; delta_ws: R*H*N floats of scratch. */
+int yv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int R, int N, int H,
+                     float scale, void* dqkv, float* delta_ws, void* stream);
+
+/* out_t[c][r] = in[r][c] (bf16), rows of out_t zero padded up to the next multiple of 64 (ld_out >= that). */
+int yv_transpose_bf16(const void* in, int rows, int cols, long long ld_in, void* out_t, long long ld_out, void* stream);
+
+/* f32 master weight (N,K) -> bf16 (N,K) working copy and bf16 transposed (K, ld_t >= round64(N)) copy. */
+int yv_cast_weights(const float* w, int N, int K, void* w_bf16, void* wt_bf16, long long ld_t, void* stream);
+
+/* x f32 (rows, cols) -> optional bf16 copy y and optional column sums (bias gradients; deterministic two-stage).
+ * ws: yv_colsum_ws_floats(rows, cols) floats. */
+size_t yv_colsum_ws_floats(int rows, int cols);
+int yv_cast_colsum(const float* x, int rows, int cols, void* y_bf16, float* colsum, int accumulate, float* ws,
+                   void* stream);
+int yv_colsum_bf16(const void* x, int rows, int cols, long long ld, float* colsum, int accumulate, float* ws,
+                   void* stream);
+
+/* LayerNorm backward: dx += dLN(dy) (f32 stream), dgamma / dbeta (D) f32; statistics recomputed from x. */
+size_t yv_layernorm_bwd_ws_floats(int rows, int D);
+int yv_layernorm_bwd(const float* x, long long ldx, const float* gamma, const void* dy, long long lddy, int rows, int D,
+                     float eps, float* dx, long long lddx, float* dgamma, float* dbeta, float* ws, void* stream);
+
+/* out (N,D) = sum over the R crops of dx (R,N,D): d pos_embed (row 0 is also d cls_token). */
+int yv_token_reduce(const float* dx, int R, int N, int D, float* out, void* stream);
+
+/* Network_Wrapper.fc backward (utils/utils.py:64-72): feats (R,ldf) f32 backbone logits, dlogits (R,nc) ->
+ * dW1 (128,1000), db1, dW2 (nc,128), db2 (f32) and d feats (R,ldd) bf16 (columns >= 1000 zero).
+ * ws: 2*R*128 floats. */
+int yv_head_bwd(const float* feats, int ldf, const float* w1t, const float* b1, const float* w2, const float* dlogits,
+                int R, int nc, float* dw1, float* db1, float* dw2, float* db2, void* dfeats_bf16, int ldd, float* ws,
+                void* stream);
 
 /* build_loss = LSCE(0.1)/6 + Focal(1,2,'mean')*5/6 (utils/trainClass.py:46-66,162-185,362-370)
  * loss = w_lsce*LSCE + w_focal*Focal (build_loss: 1/6, 5/6; each term alone: (1,0) / (0,1)).

@@ -27,7 +27,7 @@ constexpr int HD = 64;
 template <int NT>
 __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __restrict__ qkv, int N, int H, int QB,
                                                             float scale_log2e, uint16_t* __restrict__ out,
-                                                            const int32_t* __restrict__ r_dev) {
+                                                            const int32_t* __restrict__ r_dev, float* __restrict__ lse) {
     // blockIdx.x = ((crop * H + head) * QB + query block); a query block = NT waves x 32 queries = NP rows.
     // Keys/values are consumed in tiles of NP rows with an online softmax (running max m, sum l, rescaled
     // O); N <= NP (ViT-x/16: 197 <= 224) is the single-tile case and pays no rescale.
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __re
 
     // ---- normalise and store: lane owns d = 32mt + 8g + 4hh .. +3 of its query -------------
     if (q < N) {
+        if (lse && hh == 0) lse[((size_t)r * H + hd) * N + q] = m_run * scale_log2e + log2f(l_run);   // log2 domain
         const float inv = 1.0f / l_run;
         uint16_t* orow = out + ((size_t)r * N + q) * D + hd * HD;
 #pragma unroll
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __re
 }
 
 template <int NT>
-int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t* out, const int32_t* r_dev,
+int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t* out, const int32_t* r_dev, float* lse,
                 hipStream_t st) {
     constexpr int NP = NT * 32;
     const size_t lds = (size_t)NP * 128 + 64 * (size_t)(NP * 2 + 8);
@@ -178,14 +179,14 @@ int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t*
         return YV_ERR_LAUNCH;
     const int QB = (N + NP - 1) / NP;
     hipLaunchKernelGGL(kern, dim3(R * H * QB), dim3(NT * 64), lds, st, qkv, N, H, QB, scale * 1.4426950408889634f, out,
-                       r_dev);
+                       r_dev, lse);
     return yv_launch_status();
 }
 
 }  // namespace
 
-extern "C" int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev,
-                            void* stream) {
+static int attention_impl(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev, float* lse,
+                          void* stream) {
     if (!qkv || !out || R < 0 || N <= 0 || H <= 0) return YV_ERR_ARG;
     if ((long long)R * H * ((N + 255) / 256) > 0x7fffffffLL) return YV_ERR_LIMIT;
     if (R == 0) return YV_OK;
@@ -194,13 +195,23 @@ extern "C" int yv_attention(const void* qkv, int R, int N, int H, float scale, v
     hipStream_t st = (hipStream_t)stream;
     const int nt = N > 256 ? 8 : (N + 31) / 32;        // > 256 tokens: 256-row tiles, online softmax
     switch (nt) {
-        case 1: return launch_attn<1>(q, R, N, H, scale, o, r_dev, st);
-        case 2: return launch_attn<2>(q, R, N, H, scale, o, r_dev, st);
-        case 3: return launch_attn<3>(q, R, N, H, scale, o, r_dev, st);
-        case 4: return launch_attn<4>(q, R, N, H, scale, o, r_dev, st);
-        case 5: return launch_attn<5>(q, R, N, H, scale, o, r_dev, st);
-        case 6: return launch_attn<6>(q, R, N, H, scale, o, r_dev, st);
-        case 7: return launch_attn<7>(q, R, N, H, scale, o, r_dev, st);
-        default: return launch_attn<8>(q, R, N, H, scale, o, r_dev, st);
+        case 1: return launch_attn<1>(q, R, N, H, scale, o, r_dev, lse, st);
+        case 2: return launch_attn<2>(q, R, N, H, scale, o, r_dev, lse, st);
+        case 3: return launch_attn<3>(q, R, N, H, scale, o, r_dev, lse, st);
+        case 4: return launch_attn<4>(q, R, N, H, scale, o, r_dev, lse, st);
+        case 5: return launch_attn<5>(q, R, N, H, scale, o, r_dev, lse, st);
+        case 6: return launch_attn<6>(q, R, N, H, scale, o, r_dev, lse, st);
+        case 7: return launch_attn<7>(q, R, N, H, scale, o, r_dev, lse, st);
+        default: return launch_attn<8>(q, R, N, H, scale, o, r_dev, lse, st);
     }
+}
+
+extern "C" int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev,
+                            void* stream) {
+    return attention_impl(qkv, R, N, H, scale, out, r_dev, nullptr, stream);
+}
+
+extern "C" int yv_attention_train(const void* qkv, int R, int N, int H, float scale, void* out, float* lse, void* stream) {
+    if (!lse) return YV_ERR_ARG;
+    return attention_impl(qkv, R, N, H, scale, out, nullptr, lse, stream);
 }

@@ -54,6 +54,9 @@ struct GemmArgs {
     int m_mul;
     int tiles_m, tiles_n;
     int group_m;
+    const float* resf;           // f32 residual source (null: read-modify-write `out`)
+    uint16_t* aux;               // bf16 side buffer: SAVE_PRE target / GELU_BWD pre-activation
+    int ldaux;
     int staged;                  // coalesced LDS-staged epilogue usable (alignment / width checked on the host)
 };
 
@@ -70,6 +73,19 @@ __device__ __forceinline__ float gelu_f(float x) {
     const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);     // exp(-x^2/2)
     return fmaxf(x, 0.0f) - fabsf(x * (p * t * e));
 }
+// d/dx gelu(x) = Phi(x) + x * phi(x), same erfc approximation as gelu_f
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);     // exp(-x^2/2)
+    const float w = p * t * e;                                                       // 0.5*erfc(|x|/sqrt2)
+    const float cdf = x >= 0.f ? 1.0f - w : w;
+    return cdf + x * e * 0.39894228040143267794f;
+}
+
 template <int MF, int NF>
 __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[NF][MF], int M, int m0, int n0, int wrow_m,
                                          int wrow_n, int fr, int fq) {
@@ -145,9 +161,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x4 (&acc)[
         const int n = nb + i * 16 + fq * 4;
         bv[i] = ((flags & YV_EPI_BIAS) && n < g.N) ? *(const float4*)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    auto value = [&](int i, int j, float* v) {
+    auto value = [&](int i, int j, float* v, bool act = true) {
         v[0] = acc[i][j][0] + bv[i].x; v[1] = acc[i][j][1] + bv[i].y;
         v[2] = acc[i][j][2] + bv[i].z; v[3] = acc[i][j][3] + bv[i].w;
+        if (!act) return;
         if (flags & YV_EPI_SILU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
@@ -159,6 +176,25 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x4 (&acc)[
     };
     if (!(flags & (YV_EPI_OUT_F32 | YV_EPI_RES_F32))) {
         // ---- bf16 output: MF*16 rows x 128 B slab -------------------------------------------------
+        if (flags & YV_EPI_SAVE_PRE) {           // training: keep the pre-activation (GELU'(u) needs it)
+#pragma unroll
+            for (int j = 0; j < MF; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v[4];
+                    value(i, j, v, false);
+                    const int row = j * 16 + fr, c16 = i * 2 + (fq >> 1);
+                    *(uint2*)(stage + row * 128 + ((c16 ^ (row & 7)) << 4) + (fq & 1) * 8) =
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+#pragma unroll
+            for (int it = 0; it < MF * 2; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                const int m = m0 + wrow_m + row, n = nb + ch * 8;
+                const uint4 pk = *(const uint4*)(stage + row * 128 + ((ch ^ (row & 7)) << 4));
+                if (m < M && n < g.N) *(uint4*)(g.aux + (long long)m * g.ldaux + n) = pk;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < MF; ++j)
 #pragma unroll
@@ -183,6 +219,16 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x4 (&acc)[
                     for (int q = 0; q < 4; ++q)
                         o[q] = pack_bf16x2(bf16_to_f32((uint16_t)(a[q] & 0xffff)) + bf16_to_f32((uint16_t)(b[q] & 0xffff)),
                                            bf16_to_f32((uint16_t)(a[q] >> 16)) + bf16_to_f32((uint16_t)(b[q] >> 16)));
+                    pk = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+                if (flags & YV_EPI_GELU_BWD) {      // out = dg * gelu'(u), u = saved pre-activation (bf16)
+                    const uint4 uu = *(const uint4*)(g.aux + (long long)m * g.ldaux + n);
+                    const uint32_t a[4] = {pk.x, pk.y, pk.z, pk.w}, b[4] = {uu.x, uu.y, uu.z, uu.w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[q] = pack_bf16x2(bf16_to_f32((uint16_t)(a[q] & 0xffff)) * gelu_grad_f(bf16_to_f32((uint16_t)(b[q] & 0xffff))),
+                                           bf16_to_f32((uint16_t)(a[q] >> 16)) * gelu_grad_f(bf16_to_f32((uint16_t)(b[q] >> 16))));
                     pk = make_uint4(o[0], o[1], o[2], o[3]);
                 }
                 *(uint4*)((uint16_t*)g.out + (long long)m * g.ldo + n) = pk;
@@ -216,7 +262,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x4 (&acc)[
                     }
                     float* o = (float*)g.out + orow * g.ldo + n;
                     if (flags & YV_EPI_RES_F32) {
-                        const float4 x = *(const float4*)o;
+                        const float4 x = g.resf ? *(const float4*)(g.resf + orow * g.ldo + n) : *(const float4*)o;
                         v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
                     }
                     *(float4*)o = v;
@@ -536,6 +582,7 @@ bool epi_can_stage(const GemmArgs& g) {
     const int al = f32 ? 4 : 8;
     if ((g.N % al) || (g.ldo % al) || ((uintptr_t)g.out & 15)) return false;
     if ((g.flags & YV_EPI_RES_BF16) && ((g.ldres % 8) || ((uintptr_t)g.res & 15))) return false;
+    if ((g.flags & (YV_EPI_SAVE_PRE | YV_EPI_GELU_BWD)) && ((g.ldaux % 8) || ((uintptr_t)g.aux & 15))) return false;
     return true;
 }
 
@@ -557,21 +604,26 @@ extern "C" int yv_set_option(const char* key, int value) {
     return YV_ERR_ARG;
 }
 
-extern "C" int yv_linear(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out,
-                         int ldo, const float* pos, int tok, int flags, const int32_t* m_dev, int m_mul, void* stream) {
+static int linear_impl(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out, int ldo,
+                       const float* pos, int tok, int flags, const int32_t* m_dev, int m_mul, const float* res_f32,
+                       void* aux, int ldaux, hipStream_t stream) {
     if (!A || !W || !out || M < 0 || N <= 0 || K <= 0) return YV_ERR_ARG;
     if ((K & 7) || (lda & 7) || (N & 3) || (ldo & 3)) return YV_ERR_ARG;            // 16-byte operand chunks, 4-wide stores
     if ((flags & YV_EPI_BIAS) && !bias) return YV_ERR_ARG;
     if ((flags & YV_EPI_POSEMB) && (!pos || tok <= 0)) return YV_ERR_ARG;
     if (flags & (YV_EPI_SILU | YV_EPI_RES_BF16)) return YV_ERR_ARG;
+    if ((flags & (YV_EPI_SAVE_PRE | YV_EPI_GELU_BWD)) && (!aux || (flags & (YV_EPI_OUT_F32 | YV_EPI_RES_F32)))) return YV_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)out) & 15) return YV_ERR_ARG;
     if (M == 0) return YV_OK;
     GemmArgs g = {};
     g.a0 = (const uint16_t*)A; g.lda0 = lda; g.c0 = K;
     g.w = (const uint16_t*)W; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.out = out; g.ldo = ldo; g.pos = pos; g.tok = tok; g.flags = flags; g.m_dev = m_dev; g.m_mul = m_mul;
+    g.resf = res_f32; g.aux = (uint16_t*)aux; g.ldaux = ldaux;
     g.ksize = 1; g.stride = 1;
     g.staged = g_opt_staged && epi_can_stage(g);
+    if ((flags & (YV_EPI_SAVE_PRE | YV_EPI_GELU_BWD)) && (!g.staged || (K % BK) || N <= 64)) return YV_ERR_ARG;
+    if (res_f32 && (!g.staged || (K % BK) || N <= 64)) return YV_ERR_ARG;
     g.group_m = g_opt_group_m > 0 ? g_opt_group_m : 8;
     if ((K % BK) == 0 && N > 64 && g_opt_variant != 0) {
         int variant = g_opt_variant;
@@ -579,18 +631,29 @@ extern "C" int yv_linear(const void* A, int lda, const void* W, const float* bia
         // (half the L2->LDS bytes per flop); N = 768 keeps 128x128 (more workgroups, shorter tail)
         if (variant == 1 && N >= 1536 && M >= 2048) variant = 3;
         switch (variant) {
-            case 2: return launch_dma<256, 128, 4, 2>(g, (hipStream_t)stream);
-            case 3: return launch_dma<256, 256, 2, 4>(g, (hipStream_t)stream);
-            case 4: return launch_dma<128, 256, 2, 4>(g, (hipStream_t)stream);
-            case 101: return launch_dma<128, 128, 2, 2, 1>(g, (hipStream_t)stream);
-            case 102: return launch_dma<128, 128, 2, 2, 2>(g, (hipStream_t)stream);
-            case 103: return launch_dma<128, 128, 2, 2, 3>(g, (hipStream_t)stream);
-            case 104: return launch_dma<128, 128, 2, 2, 4>(g, (hipStream_t)stream);
-            case 10: return launch_dma<128, 128, 2, 2>(g, (hipStream_t)stream);     // forced 128x128
-            default: return launch_dma<128, 128, 2, 2>(g, (hipStream_t)stream);
+            case 2: return launch_dma<256, 128, 4, 2>(g, stream);
+            case 3: return launch_dma<256, 256, 2, 4>(g, stream);
+            case 4: return launch_dma<128, 256, 2, 4>(g, stream);
+            case 101: return launch_dma<128, 128, 2, 2, 1>(g, stream);
+            case 102: return launch_dma<128, 128, 2, 2, 2>(g, stream);
+            case 103: return launch_dma<128, 128, 2, 2, 3>(g, stream);
+            case 104: return launch_dma<128, 128, 2, 2, 4>(g, stream);
+            default: return launch_dma<128, 128, 2, 2>(g, stream);
         }
     }
-    return dispatch<0>(g, (hipStream_t)stream);
+    return dispatch<0>(g, stream);
+}
+
+extern "C" int yv_linear(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out,
+                         int ldo, const float* pos, int tok, int flags, const int32_t* m_dev, int m_mul, void* stream) {
+    return linear_impl(A, lda, W, bias, M, N, K, out, ldo, pos, tok, flags, m_dev, m_mul, nullptr, nullptr, 0,
+                       (hipStream_t)stream);
+}
+
+extern "C" int yv_linear_ex(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, void* out,
+                            int ldo, int flags, const float* res_f32, void* aux, int ldaux, void* stream) {
+    return linear_impl(A, lda, W, bias, M, N, K, out, ldo, nullptr, 0, flags, nullptr, 1, res_f32, aux, ldaux,
+                       (hipStream_t)stream);
 }
 
 extern "C" int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,

@@ -62,6 +62,18 @@ _SIGS = {
     "yv_wrapper_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "yv_sppf_pool": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "yv_stem_conv": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "yv_linear_ex": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "yv_attention_train": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "yv_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "yv_transpose_bf16": (_i, [_vp, _i, _i, C.c_longlong, _vp, C.c_longlong, _vp]),
+    "yv_cast_weights": (_i, [_vp, _i, _i, _vp, _vp, C.c_longlong, _vp]),
+    "yv_colsum_ws_floats": (_sz, [_i, _i]),
+    "yv_cast_colsum": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "yv_colsum_bf16": (_i, [_vp, _i, _i, C.c_longlong, _vp, _i, _vp, _vp]),
+    "yv_layernorm_bwd_ws_floats": (_sz, [_i, _i]),
+    "yv_layernorm_bwd": (_i, [_vp, C.c_longlong, _vp, _vp, C.c_longlong, _i, _i, _f, _vp, C.c_longlong, _vp, _vp, _vp, _vp]),
+    "yv_token_reduce": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "yv_head_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "yv_loss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "yv_sgd_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _vp]),
 }
@@ -343,3 +355,70 @@ def stem_conv(images: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ou
     B, H, W, _ = images.shape
     check(lib.yv_stem_conv(_p(images), B, H, W, _p(weight), _p(bias), weight.shape[1], _p(out), out.shape[-1],
                            _st()), "yv_stem_conv")
+
+
+# ------------------------------------------------------------ training ops
+EPI_SAVE_PRE, EPI_GELU_BWD = 128, 256
+
+
+def linear_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, flags: int = 0,
+              res_f32: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, M: Optional[int] = None):
+    """Training form of `linear` (separate f32 residual source, saved pre-activation, GELU backward)."""
+    _chk_dev(a, w, bias, out, res_f32, aux)
+    Mr = a.shape[0] if M is None else M
+    K, N = a.shape[1], w.shape[0]
+    if bias is not None:
+        flags |= EPI_BIAS
+    check(lib.yv_linear_ex(_p(a), a.stride(0), _p(w), _p(bias), Mr, N, K, _p(out), out.stride(0), flags, _p(res_f32),
+                           _p(aux), 0 if aux is None else aux.stride(0), _st()), "yv_linear_ex")
+    return out
+
+
+def attention_train(qkv, R, N, H, out, lse, scale=None):
+    check(lib.yv_attention_train(_p(qkv), R, N, H, float(64 ** -0.5 if scale is None else scale), _p(out), _p(lse),
+                                 _st()), "yv_attention_train")
+
+
+def attention_bwd(qkv, out, dout, lse, R, N, H, dqkv, delta_ws, scale=None):
+    check(lib.yv_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), R, N, H, float(64 ** -0.5 if scale is None else scale),
+                               _p(dqkv), _p(delta_ws), _st()), "yv_attention_bwd")
+
+
+def transpose_bf16(x: torch.Tensor, out_t: torch.Tensor, rows: Optional[int] = None):
+    """x (rows, cols) bf16 -> out_t (cols, ld >= round64(rows)) with zero padding."""
+    r = x.shape[0] if rows is None else rows
+    check(lib.yv_transpose_bf16(_p(x), r, x.shape[1], x.stride(0), _p(out_t), out_t.stride(0), _st()), "yv_transpose_bf16")
+    return out_t
+
+
+def cast_weights(w: torch.Tensor, w_bf16: torch.Tensor, wt_bf16: torch.Tensor):
+    N, K = w.shape
+    check(lib.yv_cast_weights(_p(w), N, K, _p(w_bf16), _p(wt_bf16), wt_bf16.stride(0), _st()), "yv_cast_weights")
+
+
+def cast_colsum(x: torch.Tensor, y_bf16: Optional[torch.Tensor], colsum: Optional[torch.Tensor], ws: torch.Tensor,
+                accumulate: bool = False):
+    rows, cols = x.shape
+    check(lib.yv_cast_colsum(_p(x), rows, cols, _p(y_bf16), _p(colsum), 1 if accumulate else 0, _p(ws), _st()),
+          "yv_cast_colsum")
+
+
+def colsum_bf16(x: torch.Tensor, colsum: torch.Tensor, ws: torch.Tensor, rows: Optional[int] = None,
+                accumulate: bool = False):
+    r = x.shape[0] if rows is None else rows
+    check(lib.yv_colsum_bf16(_p(x), r, x.shape[1], x.stride(0), _p(colsum), 1 if accumulate else 0, _p(ws), _st()),
+          "yv_colsum_bf16")
+
+
+def layernorm_bwd(x, ldx, gamma, dy, lddy, rows, D, dx, lddx, dgamma, dbeta, ws, eps=1e-6):
+    check(lib.yv_layernorm_bwd(_p(x), ldx, _p(gamma), _p(dy), lddy, rows, D, float(eps), _p(dx), lddx, _p(dgamma),
+                               _p(dbeta), _p(ws), _st()), "yv_layernorm_bwd")
+
+
+def token_reduce(dx, R, N, D, out):
+    check(lib.yv_token_reduce(_p(dx), R, N, D, _p(out), _st()), "yv_token_reduce")
+
+
+def head_bwd(feats, w1t, b1, w2, dlogits, R, nc, dw1, db1, dw2, db2, dfeats, ws):
+    check(lib.yv_head_bwd(_p(feats), feats.stride(0), _p(w1t), _p(b1), _p(w2), _p(dlogits), R, nc, _p(dw1), _p(db1),
+                          _p(dw2), _p(db2), _p(dfeats), dfeats.stride(0), _p(ws), _st()), "yv_head_bwd")
