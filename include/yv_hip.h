@@ -236,9 +236,9 @@ int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, f
                     float* loss, float* grad, void* stream);
 
 /* torch.optim.SGD(momentum, weight_decay) step (utils/trainClass.py:442-443), fp32, in place:
- * g += wd*p; m = first ? g : mu*m + g; p -= lr*m. */
+ * g = g*grad_scale + wd*p; m = first ? g : mu*m + g; p -= lr*m.  (grad_scale: 1/world_size after a SUM all-reduce) */
 int yv_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum, float weight_decay,
-                int first, void* stream);
+                float grad_scale, int first, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 //   yv_loss_fwd_bwd  build_loss = LSCE(0.1)/6 + Focal(alpha 1, gamma 2, mean)*5/6
 //                    utils/trainClass.py:46-66,162-185,362-370  (forward value + d/dlogits)
 //   yv_sgd_step      torch.optim.SGD(lr, momentum=0.9, weight_decay=1e-3)   utils/trainClass.py:442-443
+//                    (grad_scale = 1/world folds the data-parallel gradient mean into the update)
 // The loss is (B,5): latency-bound, one workgroup.  SGD is a 20 B/param HBM stream
 // (read p,g,m; write p,m) issued as 16-byte accesses.
 #include "yv_common.h"
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ m, size_t n, float lr, float mu, float wd,
-                                                  int first) {
+                                                  float gs, int first) {
     const size_t n4 = n >> 2;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
         if (!first) { mv = ((float4*)m)[i]; me[0] = mv.x; me[1] = mv.y; me[2] = mv.z; me[3] = mv.w; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float gq = __fadd_rn(ge[q], __fmul_rn(wd, pe[q]));
+            float gq = __fadd_rn(__fmul_rn(ge[q], gs), __fmul_rn(wd, pe[q]));
             me[q] = first ? gq : __fadd_rn(__fmul_rn(mu, me[q]), gq);
             pe[q] = __fsub_rn(pe[q], __fmul_rn(lr, me[q]));
         }
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     // tail (< 4 elements)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         size_t i = (n4 << 2) + threadIdx.x;
-        float gq = __fadd_rn(g[i], __fmul_rn(wd, p[i]));
+        float gq = __fadd_rn(__fmul_rn(g[i], gs), __fmul_rn(wd, p[i]));
         float mq = first ? gq : __fadd_rn(__fmul_rn(mu, m[i]), gq);
         m[i] = mq;
         p[i] = __fsub_rn(p[i], __fmul_rn(lr, mq));
@@ -88,7 +89,7 @@ extern "C" int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B
 }
 
 extern "C" int yv_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum,
-                           float weight_decay, int first, void* stream) {
+                           float weight_decay, float grad_scale, int first, void* stream) {
     if (!p || !g || !m) return YV_ERR_ARG;
     if (n == 0) return YV_OK;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m) & 15) return YV_ERR_ARG;
@@ -96,6 +97,6 @@ extern "C" int yv_sgd_step(float* p, const float* g, float* m, size_t n, float l
     size_t want = (n4 + 255) / 256;
     int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, n, lr, momentum,
-                       weight_decay, first);
+                       weight_decay, grad_scale, first);
     return yv_launch_status();
 }

@@ -75,7 +75,7 @@ _SIGS = {
     "yv_token_reduce": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "yv_head_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "yv_loss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
-    "yv_sgd_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _vp]),
+    "yv_sgd_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp]),
 }
 
 
@@ -266,10 +266,10 @@ def loss_fwd_bwd(logits: torch.Tensor, labels: torch.Tensor, w_lsce: float = 1.0
 
 
 def sgd_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, momentum: float = 0.9,
-             weight_decay: float = 1e-3, first: bool = False):
+             weight_decay: float = 1e-3, first: bool = False, grad_scale: float = 1.0):
     _chk_dev(p, g, m)
     check(lib.yv_sgd_step(_p(p), _p(g), _p(m), p.numel(), float(lr), float(momentum), float(weight_decay),
-                          1 if first else 0, _st()), "yv_sgd_step")
+                          float(grad_scale), 1 if first else 0, _st()), "yv_sgd_step")
 
 
 # ------------------------------------------------------------- dense math

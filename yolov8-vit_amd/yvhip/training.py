@@ -1,0 +1,257 @@
+"""ViT fine-tune step on the HIP path (reference loop utils/trainClass.py:374-420).
+
+One `VitTrainer.step(patches, labels, lr)` = forward (activations kept) -> build_loss (fused kernel) ->
+backward -> [data-parallel: bucketed gradient SUM all-reduce over RCCL, overlapped with the rest of
+backward] -> SGD(momentum 0.9, weight_decay 1e-3) on fp32 master weights -> bf16 working copies refreshed.
+
+Memory layout (sized for 288 GB of HBM: nothing is recomputed except softmax probabilities):
+  * parameters, gradients and momentum are three FLAT fp32 buffers in state-dict order (64-float aligned
+    slots): the optimizer is ONE kernel launch and all-reduce buckets are plain slices;
+  * every GEMM weight has two bf16 working copies, (N,K) for forward/wgrad layout and (K,N) for dgrad;
+  * wgrad runs on the same MFMA GEMM with the token dimension as K, fed by token-major (transposed,
+    zero padded to 64) copies of the activation and of the incoming gradient.
+Gradients arrive in exactly the reverse of the flat order (head first, patch-embed last), so a bucket is
+complete - and its all-reduce can start - as soon as backward has passed its lowest offset.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import (EPI_GELU, EPI_GELU_BWD, EPI_OUT_F32, EPI_POSEMB, EPI_RES_F32, EPI_SAVE_PRE, YvError, attention_bwd,
+               attention_train, cast_colsum, cast_weights, cls_rows, colsum_bf16, head_bwd, layernorm, layernorm_bwd, lib,
+               linear, linear_ex, loss_fwd_bwd, require_gpu, sgd_step, token_reduce, transpose_bf16, wrapper_head)
+from .engines import vit_cfg
+
+
+def _r64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class VitTrainer:
+    def __init__(self, state: Dict[str, torch.Tensor], name: str, num_classes: int = 5, img: int = 224,
+                 device: str = "cuda:0", momentum: float = 0.9, weight_decay: float = 1e-3,
+                 bucket_mb: float = 32.0):
+        require_gpu()
+        self.P_, self.D, self.L, self.H = vit_cfg(name)
+        self.name, self.nc, self.img, self.dev = name, num_classes, img, torch.device(device)
+        self.tok = (img // self.P_) ** 2
+        self.N = self.tok + 1
+        if self.N > 256:
+            raise YvError("the attention backward kernel covers N <= 256 tokens (patch-16 models)")
+        self.momentum, self.wd = momentum, weight_decay
+        self.steps = 0
+        # ---- flat fp32 parameter / gradient / momentum buffers --------------------------------
+        self.names: List[str] = list(state.keys())
+        self.shapes = {k: tuple(state[k].shape) for k in self.names}
+        self.off: Dict[str, int] = {}
+        o = 0
+        for k in self.names:
+            self.off[k] = o
+            o += _r64(state[k].numel())
+        self.total = o
+        z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.dev)
+        self.P, self.G, self.Mo = z(o), z(o), z(o)
+        for k in self.names:
+            self.p(k).copy_(state[k].to(self.dev, torch.float32))
+        # ---- bf16 working copies of the GEMM weights ---------------------------------------------
+        D = self.D
+        self.gemm_w: Dict[str, tuple] = {}                 # key -> (N, K, wb (Nalloc,K), wt (K, ldN))
+        def reg(key, N, K, n_alloc=None):
+            na = n_alloc or N
+            wb = torch.zeros((na, K), dtype=torch.bfloat16, device=self.dev)
+            wt = torch.zeros((K, _r64(na)), dtype=torch.bfloat16, device=self.dev)
+            self.gemm_w[key] = (N, K, wb, wt)
+        reg("model.patch_embed.proj.weight", D, 3 * self.P_ * self.P_)
+        for i in range(self.L):
+            b = f"model.blocks.{i}."
+            reg(b + "attn.qkv.weight", 3 * D, D); reg(b + "attn.proj.weight", D, D)
+            reg(b + "mlp.fc1.weight", 4 * D, D); reg(b + "mlp.fc2.weight", D, 4 * D)
+        reg("model.head.weight", 1000, D, n_alloc=1024)
+        self.b_head_pad = z(1024)
+        self.refresh_working_copies()
+        self._bufs: Dict[int, dict] = {}
+        self.bucket = int(bucket_mb * 1024 * 1024 / 4)
+        self._pending = []
+
+    # ---- views ----------------------------------------------------------------------------------
+    def _view(self, flat, k):
+        o = self.off[k]
+        n = 1
+        for d in self.shapes[k]:
+            n *= d
+        return flat[o:o + n].view(self.shapes[k])
+
+    def p(self, k):
+        return self._view(self.P, k)
+
+    def g(self, k):
+        return self._view(self.G, k)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: self.p(k).detach().clone() for k in self.names}
+
+    def grad_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: self.g(k).detach().clone() for k in self.names}
+
+    def refresh_working_copies(self):
+        for k, (N, K, wb, wt) in self.gemm_w.items():
+            cast_weights(self.p(k).reshape(N, K), wb, wt)
+        self.b_head_pad[:1000].copy_(self.p("model.head.bias"))
+
+    # ---- buffers ----------------------------------------------------------------------------------
+    def _buffers(self, R: int) -> dict:
+        if R in self._bufs:
+            return self._bufs[R]
+        dev, D, N, L = self.dev, self.D, self.N, self.L
+        M, Mp = R * N, _r64(R * N)
+        f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        b16 = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=dev)
+        b = dict(M=M, Mp=Mp,
+                 x=[f32(M, D) for _ in range(2 * L + 1)],                      # residual stream snapshots
+                 h1=[b16(M, D) for _ in range(L)], qkv=[b16(M, 3 * D) for _ in range(L)],
+                 o=[b16(M, D) for _ in range(L)], lse=[f32(R * self.H * N) for _ in range(L)],
+                 h2=[b16(M, D) for _ in range(L)], u=[b16(M, 4 * D) for _ in range(L)], g=[b16(M, 4 * D) for _ in range(L)],
+                 c=b16(R, D), feats=f32(R, 1024), logits=f32(R, self.nc), labels=torch.zeros(R, dtype=torch.int32, device=dev),
+                 dx=f32(M, D), dxb=b16(M, D), dwide=b16(M, 4 * D), dqkv=b16(M, 3 * D), dnar=b16(M, D),
+                 xt=b16(4 * D, Mp), dyt=b16(4 * D, Mp), delta=f32(R * self.H * N),
+                 dfeats=b16(R, 1024), dc=b16(R, D), ct=b16(D, _r64(R)), dft=b16(1024, _r64(R)),
+                 dtok=b16(R * self.tok, D), dtok32=f32(R * self.tok, D), ptok_t=b16(3 * self.P_ * self.P_, _r64(R * self.tok)),
+                 dtok_t=b16(D, _r64(R * self.tok)), dpos=f32(N, D),
+                 ws=f32(max(int(lib.yv_colsum_ws_floats(M, 4 * D)), int(lib.yv_layernorm_bwd_ws_floats(M, D)), 2 * R * 128) + 64))
+        self._bufs[R] = b
+        return b
+
+    # ---- forward (activations kept) -------------------------------------------------------------------
+    def forward(self, patches: torch.Tensor, R: int) -> torch.Tensor:
+        b = self._buffers(R)
+        D, N, tok, H, L = self.D, self.N, self.tok, self.H, self.L
+        M = R * N
+        W = lambda k: self.gemm_w[k][2]
+        x0 = b["x"][0]
+        cls_rows(self.p("model.cls_token").reshape(D), self.p("model.pos_embed").reshape(N, D), R, tok, D, x0)
+        linear(patches, W("model.patch_embed.proj.weight"), self.p("model.patch_embed.proj.bias"), x0,
+               flags=EPI_OUT_F32 | EPI_POSEMB, pos=self.p("model.pos_embed").reshape(N, D), tok=tok)
+        for i in range(L):
+            k = f"model.blocks.{i}."
+            xin, xmid, xout = b["x"][2 * i], b["x"][2 * i + 1], b["x"][2 * i + 2]
+            layernorm(xin, self.p(k + "norm1.weight"), self.p(k + "norm1.bias"), b["h1"][i], M, D, D, D)
+            linear(b["h1"][i], W(k + "attn.qkv.weight"), self.p(k + "attn.qkv.bias"), b["qkv"][i])
+            attention_train(b["qkv"][i], R, N, H, b["o"][i], b["lse"][i])
+            linear_ex(b["o"][i], W(k + "attn.proj.weight"), self.p(k + "attn.proj.bias"), xmid, flags=EPI_RES_F32, res_f32=xin)
+            layernorm(xmid, self.p(k + "norm2.weight"), self.p(k + "norm2.bias"), b["h2"][i], M, D, D, D)
+            linear_ex(b["h2"][i], W(k + "mlp.fc1.weight"), self.p(k + "mlp.fc1.bias"), b["g"][i],
+                      flags=EPI_GELU | EPI_SAVE_PRE, aux=b["u"][i])
+            linear_ex(b["g"][i], W(k + "mlp.fc2.weight"), self.p(k + "mlp.fc2.bias"), xout, flags=EPI_RES_F32, res_f32=xmid)
+        xf = b["x"][2 * L]
+        layernorm(xf, self.p("model.norm.weight"), self.p("model.norm.bias"), b["c"], R, D, N * D, D)
+        linear(b["c"], W("model.head.weight"), self.b_head_pad, b["feats"], flags=EPI_OUT_F32)
+        w1t = self.p("fc.1.weight").t().contiguous()
+        b["w1t"] = w1t
+        wrapper_head(b["feats"], w1t, self.p("fc.1.bias"), self.p("fc.3.weight"), self.p("fc.3.bias"), R, self.nc,
+                     b["logits"], b["labels"])
+        return b["logits"]
+
+    # ---- backward ---------------------------------------------------------------------------------------
+    def _wgrad(self, key: str, dy: torch.Tensor, x: torch.Tensor, rows: int, b: dict, dyt=None, xt=None):
+        """G[key] (N,K) = dy^T (N,rows) . x (rows,K): both operands transposed to token-major, MFMA GEMM."""
+        N, K = self.gemm_w[key][0], self.gemm_w[key][1]
+        rp = _r64(rows)
+        dyt = b["dyt"] if dyt is None else dyt
+        xt = b["xt"] if xt is None else xt
+        dyt_v = dyt.view(-1)[: dy.shape[1] * rp].view(dy.shape[1], rp)
+        xt_v = xt.view(-1)[: x.shape[1] * rp].view(x.shape[1], rp)
+        transpose_bf16(dy, dyt_v, rows)
+        transpose_bf16(x, xt_v, rows)
+        linear(dyt_v, xt_v, None, self.g(key).reshape(N, K), flags=EPI_OUT_F32, M=N)
+
+    def _launch_ready_buckets(self, low_offset: int):
+        """All-reduce (SUM) every bucket that lies entirely above `low_offset` (its gradients are final)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        while self._next_hi > low_offset:
+            lo = max(self._next_hi - self.bucket, 0)
+            if lo < low_offset and low_offset > 0:
+                break
+            self._pending.append(dist.all_reduce(self.G[lo:self._next_hi], op=dist.ReduceOp.SUM, async_op=True))
+            self._next_hi = lo
+            if lo == 0:
+                break
+
+    def backward(self, patches: torch.Tensor, labels: torch.Tensor, R: int) -> torch.Tensor:
+        b = self._buffers(R)
+        D, N, tok, H, L = self.D, self.N, self.tok, self.H, self.L
+        M = R * N
+        Wt = lambda k: self.gemm_w[k][3]
+        self._next_hi, self._pending = self.total, []
+        loss, dlogits = loss_fwd_bwd(b["logits"], labels)
+        # ---- Network_Wrapper.fc + backbone head -----------------------------------------------------------
+        head_bwd(b["feats"], b["w1t"], self.p("fc.1.bias"), self.p("fc.3.weight"), dlogits, R, self.nc,
+                 self.g("fc.1.weight"), self.g("fc.1.bias"), self.g("fc.3.weight"), self.g("fc.3.bias"), b["dfeats"], b["ws"])
+        self._launch_ready_buckets(self.off["fc.1.weight"])
+        colsum_bf16(b["dfeats"], b["ws"][:1024], b["ws"][1024:], rows=R)
+        self.g("model.head.bias").copy_(b["ws"][:1000])
+        self._wgrad("model.head.weight", b["dfeats"], b["c"], R, b, dyt=b["dft"], xt=b["ct"])
+        linear(b["dfeats"], Wt("model.head.weight"), None, b["dc"])
+        b["dx"].zero_()
+        layernorm_bwd(b["x"][2 * L], N * D, self.p("model.norm.weight"), b["dc"], D, R, D, b["dx"], N * D,
+                      self.g("model.norm.weight"), self.g("model.norm.bias"), b["ws"])
+        self._launch_ready_buckets(self.off["model.norm.weight"])
+        # ---- transformer blocks, last to first -------------------------------------------------------------
+        for i in reversed(range(L)):
+            k = f"model.blocks.{i}."
+            xin, xmid = b["x"][2 * i], b["x"][2 * i + 1]
+            dx, dxb = b["dx"], b["dxb"]
+            # MLP branch
+            cast_colsum(dx, dxb, self.g(k + "mlp.fc2.bias"), b["ws"])
+            self._wgrad(k + "mlp.fc2.weight", dxb, b["g"][i], M, b)
+            linear_ex(dxb, Wt(k + "mlp.fc2.weight"), None, b["dwide"], flags=EPI_GELU_BWD, aux=b["u"][i])
+            colsum_bf16(b["dwide"], self.g(k + "mlp.fc1.bias"), b["ws"])
+            self._wgrad(k + "mlp.fc1.weight", b["dwide"], b["h2"][i], M, b)
+            linear(b["dwide"], Wt(k + "mlp.fc1.weight"), None, b["dnar"])
+            layernorm_bwd(xmid, D, self.p(k + "norm2.weight"), b["dnar"], D, M, D, dx, D,
+                          self.g(k + "norm2.weight"), self.g(k + "norm2.bias"), b["ws"])
+            # attention branch
+            cast_colsum(dx, dxb, self.g(k + "attn.proj.bias"), b["ws"])
+            self._wgrad(k + "attn.proj.weight", dxb, b["o"][i], M, b)
+            linear(dxb, Wt(k + "attn.proj.weight"), None, b["dnar"])
+            attention_bwd(b["qkv"][i], b["o"][i], b["dnar"], b["lse"][i], R, N, H, b["dqkv"], b["delta"])
+            colsum_bf16(b["dqkv"], self.g(k + "attn.qkv.bias"), b["ws"])
+            self._wgrad(k + "attn.qkv.weight", b["dqkv"], b["h1"][i], M, b)
+            linear(b["dqkv"], Wt(k + "attn.qkv.weight"), None, b["dnar"])
+            layernorm_bwd(xin, D, self.p(k + "norm1.weight"), b["dnar"], D, M, D, dx, D,
+                          self.g(k + "norm1.weight"), self.g(k + "norm1.bias"), b["ws"])
+            self._launch_ready_buckets(self.off[k + "norm1.weight"])
+        # ---- embeddings -----------------------------------------------------------------------------------
+        token_reduce(b["dx"], R, N, D, b["dpos"])
+        self.g("model.pos_embed").copy_(b["dpos"].view(1, N, D))
+        self.g("model.cls_token").copy_(b["dpos"][0].view(1, 1, D))
+        b["dtok32"].copy_(b["dx"].view(R, N, D)[:, 1:, :].reshape(R * tok, D))          # drop the cls rows (copy only)
+        cast_colsum(b["dtok32"], b["dtok"], self.g("model.patch_embed.proj.bias"), b["ws"])
+        self._wgrad("model.patch_embed.proj.weight", b["dtok"], patches, R * tok, b, dyt=b["dtok_t"], xt=b["ptok_t"])
+        self._launch_ready_buckets(0)
+        return loss
+
+    # ---- optimizer ----------------------------------------------------------------------------------------
+    def optimizer_step(self, lr: float):
+        import torch.distributed as dist
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size()
+            for h in self._pending:
+                h.wait()
+        self._pending = []
+        sgd_step(self.P, self.G, self.Mo, lr, self.momentum, self.wd, first=self.steps == 0, grad_scale=1.0 / world)
+        self.steps += 1
+        self.refresh_working_copies()
+
+    def step(self, patches: torch.Tensor, labels: torch.Tensor, lr: float):
+        """One fine-tune step; `patches` (R*tok, 3*P*P) bf16 patch-major crops, `labels` (R) int32.
+        Returns (loss (1,) f32 device tensor, logits (R,nc))."""
+        R = labels.shape[0]
+        logits = self.forward(patches, R)
+        loss = self.backward(patches, labels, R)
+        self.optimizer_step(lr)
+        return loss, logits
