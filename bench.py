@@ -43,6 +43,45 @@ def cpu_baseline(yolo_sd, vit_sd, vit_name, crops, budget_s=20.0, max_images=8):
             "sample": f"{n} synthetic 640x640 images, batch-1 fp32 loop, {crops} crops/image, {dt:.1f}s"}
 
 
+def bench_train(args, rank, world, dev, dist):
+    """BASELINE.json configs[2]: ViT-B/16 fine-tune fwd+bwd+SGD, 224x224, 32 crops per GPU (256 at DP=8), bf16 compute,
+    fp32 master weights, gradient all-reduce over RCCL overlapped with backward."""
+    import yvhip
+    from yvhip import engines
+    from yvhip.dist import max_over_ranks
+    from yvhip.training import VitTrainer
+    name, R = "vit_base_patch16_224", args.batch
+    tr = VitTrainer(engines.init_vit_wrapper_state(name, 5, seed=42), name, 5, device=str(dev))
+    g = torch.Generator().manual_seed(4321 + rank)
+    patches = (torch.rand(R * tr.tok, 768, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    labels = torch.randint(0, 5, (R,), generator=g, dtype=torch.int32).to(dev)
+    for _ in range(max(args.warmup, 1)):
+        tr.step(patches, labels, 1e-4)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = tr.step(patches, labels, 1e-4)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        flop = 3.0 * 35.13e9 * R                       # fwd + bwd ~ 3 x forward (BASELINE.md section 2)
+        print(json.dumps({"metric": "ViT-B/16 fine-tune images/sec (fwd+bwd+SGD)", "value": world * R * args.steps / dt,
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "ViT-B/16 fine-tune fwd+bwd, 224x224 (BASELINE.json configs[2])",
+                                     "batch_per_gpu": R, "global_batch": R * world, "parallelism": f"dp{world}",
+                                     "loss": float(loss[0])},
+                          "model_tflops_per_gpu": flop * args.steps / dt / 1e12}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +90,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--crops", type=int, default=4, help="crops classified per image (cap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = headline metric (configs[1]); train = ViT-B/16 fine-tune step (configs[2])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,6 +107,9 @@ def main():
     import yvhip
     from yvhip import engines
     from yvhip.pipeline import DetectClassifyPipeline
+
+    if args.mode == "train":
+        return bench_train(args, rank, world, dev, dist)
 
     vit_name = "vit_base_patch16_224"
     yolo_sd = engines.init_yolo_state("n", 5, seed=42, head_gain=4.0)

@@ -5,7 +5,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from yvhip.dist import gather_objects, max_over_ranks, shard_range
+from yvhip.dist import BucketReducer, gather_objects, max_over_ranks, shard_range
 
 
 def test_shard_range_partitions():
@@ -25,6 +25,15 @@ def _worker(rank, world, port, q):
     local = [f"img{i:03d}" for i in range(lo, hi)]           # each rank "processes" its slice independently
     t = max_over_ranks(1.0 + rank)                            # slowest rank defines the step time
     allr = gather_objects(local)
+    # gradient buckets: entries become final from the end; every rank launches identical slices
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red = BucketReducer(flat, 256)
+    for low in (900, 700, 512, 100):
+        red.ready(low)
+    assert red.launched == [(744, 1000)] or red.launched[0] == (744, 1000)
+    red.finish()
+    assert [b for b in red.launched] == [(744, 1000), (488, 744), (232, 488), (0, 232)]
+    assert torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, t, [x for part in allr for x in part]))

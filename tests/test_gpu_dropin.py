@@ -140,3 +140,26 @@ def test_losses_autograd(golden):
         loss = tc.build_loss(x, y)
         (loss * 2.0).backward()
         assert torch.allclose(x.grad.cpu(), 2.0 * torch.tensor(c["grad"]), atol=1e-6, rtol=3e-5)
+
+
+def test_train_one_epoch_surface(tmp_path):
+    """utils.trainClass.train_one_epoch / valid_one_epoch with a plain loader (reference signature)."""
+    import utils.trainClass as tc
+    from yvhip import engines
+    sd = engines.init_vit_wrapper_state("vit_tiny_test", 5, seed=8)
+    p = str(tmp_path / "w.pth"); torch.save(sd, p)
+    net = tc.build_model(_CFG, pretrained=p, modelName="vit_tiny_test").to(DEV)
+    g = torch.Generator().manual_seed(3)
+    xs = (torch.rand(6, 3, 224, 224, generator=g) * 2 - 1)
+    ys = torch.nn.functional.one_hot(torch.tensor([0, 1, 2, 3, 4, 0]), 5)
+    loader = [(xs[i:i + 2], ys[i:i + 2], ["p"] * 2) for i in (0, 2, 4)] + [(xs[:1], ys[:1], ["p"])]   # last one is short
+    opt = torch.optim.SGD(net.parameters(), 0.01, momentum=0.9, weight_decay=1e-3)
+    acc0, loss0 = tc.valid_one_epoch(net, tc.build_loss, loader[:3])
+    before = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    for ep in range(3):
+        tc.train_one_epoch(net, net, loader, tc.build_loss, opt, [0.01], 2, ep, 10, True, DEV)
+    after = net.state_dict()
+    assert any(not torch.equal(before[k], after[k].detach().cpu()) for k in before)
+    acc1, loss1 = tc.valid_one_epoch(net, tc.build_loss, loader[:3])
+    assert loss1 < loss0                                            # three epochs on 6 samples reduce the loss
+    assert abs(opt.param_groups[0]["lr"] - tc.cosine_anneal_schedule(2, 10, 0.01)) < 1e-12

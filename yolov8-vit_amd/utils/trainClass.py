@@ -2,8 +2,9 @@
 
 Hot-path pieces run on the HIP kernels: `build_model`/`Network_Wrapper` (ViT engine), `build_loss` +
 `LabelSmoothingCrossEntropy` + `FocalLoss` (fused loss kernel with its analytic gradient),
-`getCorrect` (device argmax), the eval transform and `crop_image`'s integer inflate.  Dataset walking,
-XML parsing, ONNX export and the augmentation zoo are outside SURVEY.md section 8 and are not rebuilt.
+`getCorrect` (device argmax), the eval transform and `crop_image`'s integer inflate.  `train_one_epoch` / `valid_one_epoch`
+run the native fine-tune step (yvhip.training).  Dataset walking, XML parsing, ONNX export and the augmentation
+zoo are outside SURVEY.md section 8 and are not rebuilt.
 """
 import json
 import math
@@ -198,14 +199,85 @@ def valid_one_epoch(net, criterion, testloader):
 
 
 # ------------------------------------------------------------------------------------- training
+def _trainer_for(net, optimizer):
+    """One VitTrainer per wrapper module (flat fp32 master weights + momentum live in the trainer)."""
+    from yvhip.training import VitTrainer
+    tr = getattr(net, "_yv_trainer", None)
+    if tr is None:
+        mom, wd = 0.9, 1e-3                                   # utils/trainClass.py:442-443
+        if optimizer is not None and getattr(optimizer, "param_groups", None):
+            g0 = optimizer.param_groups[0]
+            mom, wd = g0.get("momentum", mom), g0.get("weight_decay", wd)
+        dev = next(net.parameters()).device
+        if dev.type != "cuda":
+            dev = torch.device("cuda", torch.cuda.current_device())
+        sd = {k: v.detach() for k, v in net.state_dict().items()}
+        tr = VitTrainer(sd, net.model.arch, net.num_class, net.model.img, device=str(dev), momentum=mom, weight_decay=wd)
+        net._yv_trainer = tr
+    return tr
+
+
 def train_one_epoch(net, netp, trainloader, CELoss, optimizer, lr, batch_size, epoch, nb_epoch, use_cuda, device):
-    """utils/trainClass.py:374-420.  The fine-tune step (ViT backward + SGD + RCCL all-reduce) is
-    SURVEY.md 8(a) rows C2-C3; its kernels are not part of this round ('what comes next')."""
-    raise yvhip.YvError("ViT backward is not built yet: train_one_epoch is unavailable in this round")
+    """utils/trainClass.py:374-420 on the HIP path: per batch (short batches skipped, :394) the LR is set from
+    `cosine_anneal_schedule(epoch, nb_epoch, lr[0])` (:400-401), then forward / build_loss / backward / SGD run
+    as ONE native step (yvhip.training.VitTrainer.step).  `CELoss` must be this module's build_loss (the fused
+    kernel implements exactly that loss).  Returns the number of correct predictions like the reference."""
+    from yvhip.modules import patchify_bf16
+    if CELoss is not build_loss:
+        raise yvhip.YvError("the native train step implements build_loss (LSCE/6 + Focal*5/6) only")
+    tr = _trainer_for(net, optimizer)
+    net.train()
+    train_loss, correct, total = 0.0, 0, 0
+    for batch_idx, (inputs, targets, path) in enumerate(trainloader):
+        if inputs.shape[0] < batch_size:
+            continue
+        cur_lr = cosine_anneal_schedule(epoch, nb_epoch, lr[0])
+        if optimizer is not None:
+            for grp in optimizer.param_groups:
+                grp['lr'] = cur_lr
+        x = inputs.to(tr.dev).float()
+        labels = targets.to(tr.dev).argmax(1).to(torch.int32).contiguous()
+        loss, logits = tr.step(patchify_bf16(x, tr.P_), labels, cur_lr)
+        eq, _ = getCorrect(logits.data, targets.to(logits.device).float().data)
+        total += targets.size(0)
+        correct += int(eq.sum())
+        train_loss += float(loss[0])
+        print('Step: %d | Loss: %.3f | Acc: %.3f%% (%d/%d)' % (
+            batch_idx, train_loss / (batch_idx + 1), 100. * float(correct) / total, correct, total))
+    net.load_state_dict(tr.state_dict())                     # so that torch.save(net.state_dict()) sees the update
+    return correct
 
 
 def train(CFG, log=False):
-    raise yvhip.YvError("ViT backward is not built yet: train() is unavailable in this round")
+    """utils/trainClass.py:424-508 walks VOC XML directories on disk (xml2pd / build_dataset): that dataset
+    front-end is outside SURVEY.md section 8 and is not rebuilt; drive `train_one_epoch` / `valid_one_epoch`
+    with any loader yielding (inputs (B,3,224,224), one-hot targets (B,nc), path)."""
+    raise yvhip.YvError("dataset walking (xml2pd/build_dataset) is out of scope: call train_one_epoch with a loader")
+
+
+def fit(net, train_loader, valid_loader, CFG, log=False, save_path=None):
+    """Epoch loop of utils/trainClass.py:459-508 for caller-provided loaders: train, validate, keep the best
+    state dict (optionally saved), write result.json when `log` (same shape as :475-490)."""
+    optimizer = torch.optim.SGD(net.parameters(), CFG.lr, momentum=0.9, weight_decay=1e-3)   # hyper-parameter carrier
+    best, results = 0.0, {}
+    for epoch_num in range(1, CFG.epoch + 1):
+        t0 = time.time()
+        train_one_epoch(net, net, train_loader, build_loss, optimizer, [CFG.lr], CFG.train_bs, epoch_num - 1, CFG.epoch,
+                        True, CFG.device)
+        val_acc, val_loss = valid_one_epoch(net, build_loss, valid_loader)
+        results[epoch_num] = {'train_acc': "N/A", 'val_acc': val_acc, 'loss': val_loss}
+        if log:
+            try:
+                with open(log if isinstance(log, str) else '/app/train/result.json', 'w') as f:
+                    json.dump(results, f, indent=4)
+            except IOError as e:
+                print(f"Error: could not write result.json: {e}")
+        if val_acc > best:
+            best = val_acc
+            if save_path:
+                torch.save(net.state_dict(), save_path)
+        print("epoch:{}, time:{:.2f}s, best_val_acc:{:.2f}%\n".format(epoch_num, time.time() - t0, best), flush=True)
+    return results
 
 
 def retrain(log=False):

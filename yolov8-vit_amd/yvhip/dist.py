@@ -39,3 +39,37 @@ def gather_objects(local: list) -> List[list]:
     out: List[list] = [None] * dist.get_world_size()
     dist.all_gather_object(out, local)
     return out
+
+
+class BucketReducer:
+    """Bucketed SUM all-reduce of one flat gradient buffer whose entries become final from the END towards
+    the start (backward visits parameters in reverse order).  `ready(low)` launches, asynchronously, every
+    bucket that lies entirely at or above offset `low`; `finish()` waits for all of them.  Buckets are
+    fixed slices counted from the end, so every rank issues the same collectives in the same order."""
+
+    def __init__(self, flat: torch.Tensor, bucket_elems: int):
+        self.flat, self.bucket = flat, max(int(bucket_elems), 1)
+        self.reset()
+
+    def reset(self):
+        self.next_hi = self.flat.numel()
+        self.pending = []
+        self.launched = []                      # (lo, hi) in launch order (for tests / tracing)
+
+    def ready(self, low: int):
+        import torch.distributed as dist
+        active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        while self.next_hi > 0:
+            lo = max(self.next_hi - self.bucket, 0)
+            if lo < low:
+                break
+            if active:
+                self.pending.append(dist.all_reduce(self.flat[lo:self.next_hi], op=dist.ReduceOp.SUM, async_op=True))
+            self.launched.append((lo, self.next_hi))
+            self.next_hi = lo
+
+    def finish(self):
+        self.ready(0)
+        for h in self.pending:
+            h.wait()
+        self.pending = []

@@ -72,8 +72,8 @@ class VitTrainer:
         self.b_head_pad = z(1024)
         self.refresh_working_copies()
         self._bufs: Dict[int, dict] = {}
-        self.bucket = int(bucket_mb * 1024 * 1024 / 4)
-        self._pending = []
+        from .dist import BucketReducer
+        self.reducer = BucketReducer(self.G, int(bucket_mb * 1024 * 1024 / 4))
 
     # ---- views ----------------------------------------------------------------------------------
     def _view(self, flat, k):
@@ -167,25 +167,15 @@ class VitTrainer:
         linear(dyt_v, xt_v, None, self.g(key).reshape(N, K), flags=EPI_OUT_F32, M=N)
 
     def _launch_ready_buckets(self, low_offset: int):
-        """All-reduce (SUM) every bucket that lies entirely above `low_offset` (its gradients are final)."""
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        while self._next_hi > low_offset:
-            lo = max(self._next_hi - self.bucket, 0)
-            if lo < low_offset and low_offset > 0:
-                break
-            self._pending.append(dist.all_reduce(self.G[lo:self._next_hi], op=dist.ReduceOp.SUM, async_op=True))
-            self._next_hi = lo
-            if lo == 0:
-                break
+        """Gradients at offsets >= low_offset are final: start their all-reduce while backward continues."""
+        self.reducer.ready(low_offset)
 
     def backward(self, patches: torch.Tensor, labels: torch.Tensor, R: int) -> torch.Tensor:
         b = self._buffers(R)
         D, N, tok, H, L = self.D, self.N, self.tok, self.H, self.L
         M = R * N
         Wt = lambda k: self.gemm_w[k][3]
-        self._next_hi, self._pending = self.total, []
+        self.reducer.reset()
         loss, dlogits = loss_fwd_bwd(b["logits"], labels)
         # ---- Network_Wrapper.fc + backbone head -----------------------------------------------------------
         head_bwd(b["feats"], b["w1t"], self.p("fc.1.bias"), self.p("fc.3.weight"), dlogits, R, self.nc,
@@ -231,18 +221,13 @@ class VitTrainer:
         b["dtok32"].copy_(b["dx"].view(R, N, D)[:, 1:, :].reshape(R * tok, D))          # drop the cls rows (copy only)
         cast_colsum(b["dtok32"], b["dtok"], self.g("model.patch_embed.proj.bias"), b["ws"])
         self._wgrad("model.patch_embed.proj.weight", b["dtok"], patches, R * tok, b, dyt=b["dtok_t"], xt=b["ptok_t"])
-        self._launch_ready_buckets(0)
         return loss
 
     # ---- optimizer ----------------------------------------------------------------------------------------
     def optimizer_step(self, lr: float):
         import torch.distributed as dist
-        world = 1
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size()
-            for h in self._pending:
-                h.wait()
-        self._pending = []
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.reducer.finish()
         sgd_step(self.P, self.G, self.Mo, lr, self.momentum, self.wd, first=self.steps == 0, grad_scale=1.0 / world)
         self.steps += 1
         self.refresh_working_copies()
