@@ -634,6 +634,10 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
             case 2: return launch_dma<256, 128, 4, 2>(g, stream);
             case 3: return launch_dma<256, 256, 2, 4>(g, stream);
             case 4: return launch_dma<128, 256, 2, 4>(g, stream);
+            case 201: return launch_dma<256, 256, 2, 4, 1>(g, stream);
+            case 202: return launch_dma<256, 256, 2, 4, 2>(g, stream);
+            case 203: return launch_dma<256, 256, 2, 4, 3>(g, stream);
+            case 204: return launch_dma<256, 256, 2, 4, 4>(g, stream);
             case 101: return launch_dma<128, 128, 2, 2, 1>(g, stream);
             case 102: return launch_dma<128, 128, 2, 2, 2>(g, stream);
             case 103: return launch_dma<128, 128, 2, 2, 3>(g, stream);

@@ -210,11 +210,27 @@ __global__ __launch_bounds__(EN_THREADS) void efficient_nms_kernel(
         out_labels[(size_t)b * max_out + i] = 0;
     }
 
-    // candidates above the score threshold
+    // every thread caches the keys of its candidates in registers (A*nc <= 48K: YOLOv8 at 640 with nc <= 5);
+    // larger problems re-read the scores from L2 each pass
+    constexpr int EN_CACHE = 48;
+    const bool cached = chunks <= EN_CACHE;
+    uint32_t kreg[EN_CACHE];
     uint32_t mine = 0;
-    for (int c = 0; c < chunks; ++c) {
-        int i = c * EN_THREADS + tid;
-        if (i < total && S[i] > score_thr) ++mine;
+#pragma unroll
+    for (int c = 0; c < EN_CACHE; ++c) {
+        kreg[c] = 0xFFFFFFFFu;                                    // sentinel: not a candidate
+        const int i = c * EN_THREADS + tid;
+        if (c < chunks && i < total) {
+            const float v = S[i];
+            if (v > score_thr) { kreg[c] = desc_key(v); ++mine; }
+        }
+    }
+    if (!cached) {
+        mine = 0;
+        for (int c = 0; c < chunks; ++c) {
+            const int i = c * EN_THREADS + tid;
+            if (i < total && S[i] > score_thr) ++mine;
+        }
     }
     if (tid == 0) sh->total_cnt = 0;
     __syncthreads();
@@ -223,53 +239,46 @@ __global__ __launch_bounds__(EN_THREADS) void efficient_nms_kernel(
     const uint32_t cnt = sh->total_cnt;
     const uint32_t K = (uint32_t)pre_topk;
 
-    // radix select of the K-th best 32-bit score key (3 digits: 11 + 11 + 10 bits)
+    // binary radix select of the K-th best 32-bit score key: 32 counting passes over register-resident keys
+    // (no histogram: random-weight detectors put every score into a handful of bins and LDS-atomic
+    // histograms serialise on them).  Result: key_star and how many of the keys == key_star to take.
     uint32_t key_star = 0xFFFFFFFFu, need_eq = 0xFFFFFFFFu;      // take everything by default
     const bool select = cnt > K;
     if (select) {
         uint32_t prefix = 0, need = K;
-        const int bits[3] = {11, 11, 10};
-        int consumed = 0;
-        for (int lvl = 0; lvl < 3; ++lvl) {
-            const int nb = bits[lvl], nbins = 1 << nb, shift = 32 - consumed - nb;
-            for (int i = tid; i < nbins; i += EN_THREADS) sh->hist[i] = 0;
-            __syncthreads();
-            for (int c = 0; c < chunks; ++c) {
-                int i = c * EN_THREADS + tid;
-                if (i < total) {
-                    float v = S[i];
-                    if (v > score_thr) {
-                        uint32_t k = desc_key(v);
-                        bool in_prefix = consumed == 0 ? true : ((k >> (32 - consumed)) == prefix);
-                        if (in_prefix) atomicAdd(&sh->hist[(k >> shift) & (nbins - 1)], 1u);
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+            uint32_t c0 = 0;
+            if (cached) {
+#pragma unroll
+                for (int c = 0; c < EN_CACHE; ++c) {
+                    const uint32_t k = kreg[c];
+                    const bool cand = k != 0xFFFFFFFFu;        // a score > threshold is never NaN, so no real key is ~0
+                    c0 += (cand && ((k & hi_mask) == prefix) && !((k >> bit) & 1u)) ? 1u : 0u;
+                }
+            } else {
+                for (int c = 0; c < chunks; ++c) {
+                    const int i = c * EN_THREADS + tid;
+                    if (i < total) {
+                        const float v = S[i];
+                        if (v > score_thr) {
+                            const uint32_t k = desc_key(v);
+                            c0 += (((k & hi_mask) == prefix) && !((k >> bit) & 1u)) ? 1u : 0u;
+                        }
                     }
                 }
             }
+            // block sum (uniform result)
+            uint32_t w = c0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
             __syncthreads();
-            if (tid < 64) {
-                const int per = nbins / 64, base = tid * per;
-                uint32_t local = 0;
-                for (int q = 0; q < per; ++q) local += sh->hist[base + q];
-                uint32_t incl = local;
-                for (int o = 1; o < 64; o <<= 1) {
-                    uint32_t v = __shfl_up(incl, o, 64);
-                    if (tid >= o) incl += v;
-                }
-                uint32_t excl = incl - local;
-                if (excl < need && incl >= need) {
-                    uint32_t cacc = excl;
-                    for (int q = 0; q < per; ++q) {
-                        uint32_t h = sh->hist[base + q];
-                        if (cacc + h >= need) { sh->sel_bin = base + q; sh->sel_before = cacc; break; }
-                        cacc += h;
-                    }
-                }
-            }
+            if ((tid & 63) == 0) sh->wave_cnt[tid >> 6] = w;
             __syncthreads();
-            prefix = (prefix << nb) | sh->sel_bin;
-            need -= sh->sel_before;
-            consumed += nb;
-            __syncthreads();
+            uint32_t t0 = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t0 += sh->wave_cnt[q];
+            if (need > t0) { need -= t0; prefix |= (1u << bit); }
         }
         key_star = prefix;
         need_eq = need;              // how many of the candidates with key == key_star to take (index order)
