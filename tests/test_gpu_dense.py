@@ -219,3 +219,25 @@ def test_stem_conv(yv):
     out = torch.zeros(B, H // 2, H // 2, 16, dtype=torch.bfloat16, device=DEV)
     yv.stem_conv(img.to(DEV), w.permute(2, 3, 1, 0).reshape(27, 16).contiguous().to(DEV), b.to(DEV), out)
     assert rel_l2(out.permute(0, 3, 1, 2).float().cpu(), ref) < 3e-3
+
+
+def test_gemm_8phase_race_screen(yv):
+    """The staggered 8-phase kernel must be bit-identical to the simple 2-stage 256x256 kernel (same per-element
+    accumulation order) on every repetition: an LDS read-before-landed or restage-before-read race would show
+    up as a mismatch (tools/gemm_race_screen.py is the long version)."""
+    g = torch.Generator().manual_seed(0)
+    try:
+        for (m, n, k) in ((6304, 2304, 768), (2500, 3072, 768), (300, 256, 192), (257, 264, 64), (3000, 768, 3072)):
+            a = bf(torch.randn(m, k, generator=g)).to(DEV); w = bf(torch.randn(n, k, generator=g) * 0.05).to(DEV)
+            bias = torch.randn(n, generator=g).to(DEV)
+            ref = torch.zeros(m, n, dtype=torch.bfloat16, device=DEV)
+            yv.set_option("linear_variant", 3)
+            yv.linear(a, w, bias, ref)
+            assert rel_l2(ref.cpu().float(), a.cpu().float() @ w.cpu().float().t() + bias.cpu()) < 4e-3
+            yv.set_option("linear_variant", 8)
+            for _ in range(10):
+                out = torch.full((m, n), 3.0, dtype=torch.bfloat16, device=DEV)
+                yv.linear(a, w, bias, out)
+                assert torch.equal(out, ref), (m, n, k)
+    finally:
+        yv.set_option("linear_variant", 1)

@@ -548,6 +548,186 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
     else if (acc[0][0][0] == 12345.678f) finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 x 64 "8-phase" kernel (cdna_hip_programming.md section 5 template, re-derived for this operand
+// convention).  8 waves = 2 groups (wm = 0/1, 128 activation rows each) x 4 (64 weight rows each); one
+// workgroup per CU, 128 KB of LDS = 2 stages x {A tile, W tile}.  A K tile is consumed in 4 phases, one
+// 64 x 32 quadrant of the wave tile each (16 MFMAs): (m0,n0) (m0,n1) (m1,n1) (m1,n0); every phase is
+//     [ds_read this phase's operand half | issue ONE half-tile of LDS-DMA] barrier [16 MFMA] barrier
+// and the two wave groups run ONE BARRIER APART, so that on every SIMD one wave is in its MFMA segment while
+// its partner reads LDS / issues DMA.  The DMA stream runs 3 half-tiles ahead and is retired once per K
+// tile by a COUNTED s_waitcnt vmcnt(6) (never 0 in the loop), raw s_barrier (a __syncthreads would drain).
+//
+// Half-tiles: A-half h = rows {wm*128 + h*64 + [0,64)} (both groups), W-half h = rows {wn*64 + h*32 + [0,32)}:
+// each half holds what every wave reads in ONE phase, so it dies as a unit:
+//     phase 1 reads A0,W0   phase 2 reads W1   phase 3 reads A1   phase 4 reads nothing  (W0,W1 stay in VGPRs)
+//     restage (one phase after the last read; reads are retired by lgkmcnt(0) BEFORE the phase's first barrier):
+//     phase 1: A1(t+1)   phase 2: A0(t+2)   phase 3: W0(t+2)   phase 4: W1(t+2), then vmcnt(6) = tile t+1 landed
+// RAW: a half-tile is read at the earliest one phase after the wait that retires it (two barriers later, which
+// covers the one-barrier stagger between the groups).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, MF = 8, NF = 4;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int M = g.M;
+    if (g.m_dev) { long long md = (long long)g.m_dev[0] * g.m_mul; M = md < M ? (int)md : M; }
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    int tm, tn;
+    {
+        const int GM = g.group_m, per = GM * g.tiles_n;
+        const int grp = bid / per, first = grp * GM;
+        const int gsz = (g.tiles_m - first) < GM ? (g.tiles_m - first) : GM;
+        const int in = bid - grp * per;
+        tm = first + in % gsz;
+        tn = in / gsz;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= M) return;
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wrow_m = wm * 128, wrow_n = wn * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int lrow = lane >> 3, lch = lane & 7;
+
+    // ---- DMA descriptors: 4 half-tile kinds x 2 wave-instructions (8 rows x 128 B each) -------------------------
+    const uint16_t* src[4][2];        // [A0, A1, W0, W1][j]
+    int dst[4][2];                    // byte offset inside a stage
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rh = (wave * 2 + j) * 8 + lrow;                    // row inside the 128-row half-tile
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ra = (rh >> 6) * 128 + h * 64 + (rh & 63);     // A tile row
+            int m = m0 + ra;
+            m = m < g.M ? m : g.M - 1;
+            src[h][j] = g.a0 + (long long)m * g.lda0 + ((lch ^ (ra & 7)) << 3);
+            dst[h][j] = (ra - lrow) * 128;
+            const int rw = (rh >> 5) * 64 + h * 32 + (rh & 31);      // W tile row
+            int n = n0 + rw;
+            n = n < g.N ? n : g.N - 1;
+            src[2 + h][j] = g.w + (long long)n * g.K + ((lch ^ (rw & 7)) << 3);
+            dst[2 + h][j] = A_BYTES + (rw - lrow) * 128;
+        }
+    }
+    const int nk = g.K / BK;
+    auto dma = [&](int kind, int kt) {               // one half-tile of K tile kt into stage kt & 1
+        if (kt >= nk) return;
+        unsigned char* base = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][j] + kt * BK), (lptr_t)(base + dst[kind][j]), 16, 0, 0);
+    };
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[4][2];                  // current activation half: 4 fragments x 2 k-steps
+    bf16x8 fw[4][2];                  // both weight halves: fragments 0,1 = n0 ; 2,3 = n1
+
+    auto read_a = [&](const unsigned char* A, int h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = wrow_m + h * 64 + j * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[j][ks] = *(const bf16x8*)(A + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+        }
+    };
+    auto read_w = [&](const unsigned char* W, int h) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = wrow_n + h * 32 + i * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fw[h * 2 + i][ks] = *(const bf16x8*)(W + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+        }
+    };
+    auto mma = [&](int mh, int nh) {                 // quadrant (mh, nh): 4 x 2 accumulators x 2 k-steps
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[nh * 2 + i][mh * 4 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nh * 2 + i][ks], fa[j][ks], acc[nh * 2 + i][mh * 4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // end of a read segment: retire this wave's LDS reads, then the phase's first barrier
+    auto sync_reads = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync_mma = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: tile 0 complete, first three half-tiles of tile 1 in flight -------------------------------------
+    dma(0, 0); dma(2, 0); dma(3, 0); dma(1, 0);
+    dma(0, 1); dma(2, 1); dma(3, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    if (wm == 1) bar();                               // group 1 runs one barrier behind group 0
+
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* A = smem + (t & 1) * STAGE;
+        const unsigned char* W = A + A_BYTES;
+        // phase 1: (m0, n0)
+        read_a(A, 0); read_w(W, 0);
+        dma(1, t + 1);
+        sync_reads();
+        mma(0, 0);
+        sync_mma();
+        // phase 2: (m0, n1)
+        read_w(W, 1);
+        dma(0, t + 2);
+        sync_reads();
+        mma(0, 1);
+        sync_mma();
+        // phase 3: (m1, n1)
+        read_a(A, 1);
+        dma(2, t + 2);
+        sync_reads();
+        mma(1, 1);
+        sync_mma();
+        // phase 4: (m1, n0) - operands already in registers; retire the DMA stream down to 3 half-tiles
+        dma(3, t + 2);
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sync_reads();
+        mma(1, 0);
+        sync_mma();
+    }
+    if (wm == 0) bar();                               // group 0 waits for group 1's last phase
+    finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
+}
+
+int launch_8phase(GemmArgs& g, hipStream_t st) {
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 255) / 256;
+    const size_t lds = 2 * (size_t)(256 + 256) * 128;
+    if (hipFuncSetAttribute((const void*)gemm_8phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return YV_ERR_LAUNCH;
+    hipLaunchKernelGGL(gemm_8phase_kernel, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
+    return yv_launch_status();
+}
+
 template <int BM, int BN, int WM, int WN, int ABL = 0>
 int launch_dma(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
@@ -629,11 +809,12 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
         int variant = g_opt_variant;
         // auto (measured on the ViT-B/16 shapes, tools/gemm_bench.py): wide outputs amortise a 256x256 tile
         // (half the L2->LDS bytes per flop); N = 768 keeps 128x128 (more workgroups, shorter tail)
-        if (variant == 1 && N >= 1536 && M >= 2048) variant = 3;
+        if (variant == 1 && N >= 1536 && M >= 2048) variant = 8;       // staggered 8-phase 256x256 kernel
         switch (variant) {
             case 2: return launch_dma<256, 128, 4, 2>(g, stream);
             case 3: return launch_dma<256, 256, 2, 4>(g, stream);
             case 4: return launch_dma<128, 256, 2, 4>(g, stream);
+            case 8: return launch_8phase(g, stream);
             case 201: return launch_dma<256, 256, 2, 4, 1>(g, stream);
             case 202: return launch_dma<256, 256, 2, 4, 2>(g, stream);
             case 203: return launch_dma<256, 256, 2, 4, 3>(g, stream);
