@@ -27,6 +27,8 @@ constexpr int BK = 64;            // bf16 elements per K step
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
 int g_opt_group_m = 8;
 int g_opt_staged = 1;
+int g_opt_wide_min = 1 << 30, g_opt_wide_max = 1 << 30; // N range that takes the 8-phase 256x256 kernel (off by
+                                                          // default: end-to-end A/B, tools/e2e_ab.py, favours 128x128)
 constexpr int THREADS = 256;
 
 struct GemmArgs {
@@ -781,6 +783,8 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!strcmp(key, "linear_variant")) { g_opt_variant = value; return YV_OK; }
     if (!strcmp(key, "linear_group_m")) { g_opt_group_m = value; return YV_OK; }
     if (!strcmp(key, "staged_epilogue")) { g_opt_staged = value; return YV_OK; }
+    if (!strcmp(key, "linear_wide_min_n")) { g_opt_wide_min = value; return YV_OK; }
+    if (!strcmp(key, "linear_wide_max_n")) { g_opt_wide_max = value; return YV_OK; }
     return YV_ERR_ARG;
 }
 
@@ -807,9 +811,10 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
     g.group_m = g_opt_group_m > 0 ? g_opt_group_m : 8;
     if ((K % BK) == 0 && N > 64 && g_opt_variant != 0) {
         int variant = g_opt_variant;
-        // auto (measured on the ViT-B/16 shapes, tools/gemm_bench.py): wide outputs amortise a 256x256 tile
-        // (half the L2->LDS bytes per flop); N = 768 keeps 128x128 (more workgroups, shorter tail)
-        if (variant == 1 && N >= 1536 && M >= 2048) variant = 8;       // staggered 8-phase 256x256 kernel
+        // auto: 128x128 tiles, two workgroups per CU (one workgroup's epilogue overlaps the other's main loop).
+        // Isolated, the 8-phase 256x256 kernel is 3-13 % faster on N >= 1536, but inside the pipeline (operands
+        // cold in L2, GELU / residual epilogues) the interleaved end-to-end A/B measures it 1-2 % slower.
+        if (variant == 1 && N >= g_opt_wide_min && N <= g_opt_wide_max && M >= 2048) variant = 8;   // 8-phase 256x256
         switch (variant) {
             case 2: return launch_dma<256, 128, 4, 2>(g, stream);
             case 3: return launch_dma<256, 256, 2, 4>(g, stream);
