@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--crops", type=int, default=4, help="crops classified per image (cap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="single stream: no detector/classifier overlap across batches")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = headline metric (configs[1]); train = ViT-B/16 fine-tune step (configs[2])")
     args = ap.parse_args()
@@ -106,7 +107,7 @@ def main():
 
     import yvhip
     from yvhip import engines
-    from yvhip.pipeline import DetectClassifyPipeline
+    from yvhip.pipeline import DetectClassifyPipeline, PipelinedRunner
 
     if args.mode == "train":
         return bench_train(args, rank, world, dev, dist)
@@ -125,8 +126,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    runner = None if args.no_overlap else PipelinedRunner(pipe)
+    step = pipe if runner is None else runner.submit
     for _ in range(max(args.warmup, 1)):
-        out = pipe(images)
+        out = step(images)
     torch.cuda.synchronize()
     crops_step = int(out["crop_total"][0])
 
@@ -137,7 +140,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipe(images)
+        out = step(images)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -165,6 +168,7 @@ def main():
             "config": {"workload": "YOLOv8n(nc=5)+ViT-B/16 end-to-end inference, 640x640, bf16 "
                                    "(BASELINE.json configs[1])", "batch_per_gpu": B, "global_batch": B * world,
                        "crops_per_image": R, "crops_per_step_rank0": crops_step, "parallelism": f"dp{world}",
+                       "schedule": "single stream" if runner is None else "2 HIP streams: detector of batch i+1 overlaps classifier of batch i",
                        "weights": "random-init, seed 42"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,

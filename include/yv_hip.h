@@ -142,6 +142,12 @@ int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout,
               const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res, int res_ld,
               int flags, void* stream);
 
+/* Same, with a caller-owned f32 workspace: deep small-resolution layers then run split-K (K range sliced over
+ * several workgroups per tile + a reduce/epilogue pass).  ws_bytes >= 8 * M * Cout * 4 enables every split. */
+int yv_conv2d_ws(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
+                 const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res, int res_ld,
+                 int flags, void* ws, size_t ws_bytes, void* stream);
+
 /* Linear: out[M,N] = A[M,K] @ W[N,K]^T (+bias)(+GELU)(+residual) on MFMA
  * (timm Attention.qkv/proj, Mlp.fc1/fc2, head; README.md:21-35).
  * A (M,K) bf16 row stride lda; W (N,K) bf16; bias (N) f32.

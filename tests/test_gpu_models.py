@@ -77,3 +77,30 @@ def test_yolo_kat_param_count():
     from yvhip import engines
     tot = sum(ci * co * k * k + co for _, ci, co, k in engines.yolo_conv_keys("n", 5)) + 16
     assert tot == 3006623                                           # KAT-1, test.ipynb:12
+
+
+def test_pipelined_runner_matches_single_stream():
+    """Two-stream schedule (detector of batch i+1 overlapping classifier of batch i) and the split-classifier
+    option must produce exactly the single-stream results for every batch in flight."""
+    from yvhip import engines
+    from yvhip.pipeline import DetectClassifyPipeline, PipelinedRunner
+    name, S, B = "vit_tiny_test", 128, 4
+    pipe = DetectClassifyPipeline(engines.YoloEngine(engines.init_yolo_state("n", 5, 3, 4.0), "n", 5, S, DEV),
+                                  [engines.VitEngine(engines.init_vit_wrapper_state(name, 5, 4), name, 5, device=DEV)],
+                                  max_crops_per_image=3)
+    g = torch.Generator().manual_seed(11)
+    batches = [torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).to(DEV) for _ in range(5)]
+    keys = ("det_count", "det_box", "det_score", "crop_list", "crop_total", "cls_logits", "cls_label")
+    ref = []
+    for im in batches:
+        o = pipe(im)
+        torch.cuda.synchronize()
+        ref.append({k: o[k].clone() for k in keys})
+    for split in (False, True):
+        runner = PipelinedRunner(pipe, split_classifier=split)
+        outs = [runner.submit(im) for im in batches]               # all five in flight back to back
+        runner.sync()
+        for o, r in zip(outs, ref):
+            assert o["done"].query()
+            for k in keys:
+                assert torch.equal(o[k], r[k]), (split, k)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "yolov8-vit_amd"))
 import torch
 import yvhip
 from yvhip import engines
-from yvhip.pipeline import DetectClassifyPipeline
+from yvhip.pipeline import DetectClassifyPipeline, PipelinedRunner
 dev = "cuda:0"
 name = "vit_base_patch16_224"
 pipe = DetectClassifyPipeline(engines.YoloEngine(engines.init_yolo_state("n", 5, 42, 4.0), "n", 5, 640, dev),
@@ -14,19 +14,19 @@ pipe = DetectClassifyPipeline(engines.YoloEngine(engines.init_yolo_state("n", 5,
                               max_crops_per_image=4)
 g = torch.Generator().manual_seed(1234)
 images = torch.randint(0, 256, (32, 640, 640, 3), generator=g, dtype=torch.uint8).to(dev)
-opts = [("gm8", (1, 8)), ("gm4", (1, 4)), ("gm16", (1, 16)), ("gm2", (1, 2)), ("gm32", (1, 32)), ("8ph wide", (1, 8, 1536))]
+runner = PipelinedRunner(pipe)
+r_split = PipelinedRunner(pipe, split_classifier=True)
+opts = [("single stream", pipe), ("two streams", runner.submit), ("two streams + split ViT", r_split.submit)]
 res = {k: [] for k, _ in opts}
 for _ in range(3):
     pipe(images)
 torch.cuda.synchronize()
 for rd in range(6):
     for k, v in opts:
-        yvhip.set_option("linear_variant", v[0]); yvhip.set_option("linear_group_m", v[1])
-        yvhip.set_option("linear_wide_min_n", v[2] if len(v) > 2 else 1 << 30)
-        pipe(images); torch.cuda.synchronize()
+        v(images); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(8):
-            pipe(images)
+            v(images)
         torch.cuda.synchronize()
         res[k].append((time.perf_counter() - t0) / 8 * 1e3)
 for k, ts in res.items():

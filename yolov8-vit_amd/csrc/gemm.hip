@@ -27,6 +27,7 @@ constexpr int BK = 64;            // bf16 elements per K step
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
 int g_opt_group_m = 8;
 int g_opt_staged = 1;
+int g_opt_splitk = 0;           // measured neutral end-to-end (tools/e2e_ab.py): the reduce pass costs what the shorter chain saves
 int g_opt_wide_min = 1 << 30, g_opt_wide_max = 1 << 30; // N range that takes the 8-phase 256x256 kernel (off by
                                                           // default: end-to-end A/B, tools/e2e_ab.py, favours 128x128)
 constexpr int THREADS = 256;
@@ -59,6 +60,8 @@ struct GemmArgs {
     const float* resf;           // f32 residual source (null: read-modify-write `out`)
     uint16_t* aux;               // bf16 side buffer: SAVE_PRE target / GELU_BWD pre-activation
     int ldaux;
+    int splitk;                  // conv only: K range split over `splitk` workgroups per tile (partials in `partial`)
+    float* partial;              // (splitk, M, N) f32
     int staged;                  // coalesced LDS-staged epilogue usable (alignment / width checked on the host)
 };
 
@@ -306,6 +309,9 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
     }
+    const int S = g.splitk > 1 ? g.splitk : 1;
+    const int slice = bid % S;                 // K slices of one tile are neighbours: their A/W rows share L2
+    bid /= S;
     const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     if (m0 >= M) return;
@@ -395,12 +401,13 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
     const int wrow_m = wm * (BM / WM), wrow_n = wn * (BN / WN);
     const int fr = lane & 15, fq = lane >> 4;
 
-    const int nk = (g.K + BK - 1) / BK;
-    load_tile(0);
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * slice / S), nk = (int)((long long)nk_all * (slice + 1) / S);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
         const unsigned char* A = smem + cur * (A_BYTES + W_BYTES);
         const unsigned char* W = A + A_BYTES;
@@ -428,7 +435,47 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
+    if (S > 1) {                               // raw partial sums; bias / activation happen in splitk_reduce_kernel
+        float* P = g.partial + (long long)slice * M * g.N;
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int m = m0 + wrow_m + j * 16 + fr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int n = n0 + wrow_n + i * 16 + fq * 4;
+                if (n < g.N) *(float4*)(P + (long long)m * g.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    }
     finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
+}
+
+// second stage of a split-K conv: sum the K slices, then the usual epilogue (bias, SiLU, bf16 shortcut, store)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = g.N >> 2;
+    if (i >= (long long)g.M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < g.splitk; ++s) {
+        const float4 p = *(const float4*)(g.partial + ((long long)s * g.M + m) * g.N + n);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const int flags = g.flags;
+    if (flags & YV_EPI_BIAS) {
+        const float4 b = *(const float4*)(g.bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (flags & YV_EPI_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    if (flags & YV_EPI_RES_BF16) {
+        const uint2 rr = *(const uint2*)(g.res + (long long)m * g.ldres + n);
+        v.x += bf16_to_f32((uint16_t)(rr.x & 0xffff)); v.y += bf16_to_f32((uint16_t)(rr.x >> 16));
+        v.z += bf16_to_f32((uint16_t)(rr.y & 0xffff)); v.w += bf16_to_f32((uint16_t)(rr.y >> 16));
+    }
+    if (flags & YV_EPI_OUT_F32) *(float4*)((float*)g.out + (long long)m * g.ldo + n) = v;
+    else *(uint2*)((uint16_t*)g.out + (long long)m * g.ldo + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
 }
 
 
@@ -753,7 +800,12 @@ int launch(GemmArgs& g, hipStream_t st) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return YV_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(THREADS), lds, st, g);
+    const int S = g.splitk > 1 ? g.splitk : 1;
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * S), dim3(THREADS), lds, st, g);
+    if (S > 1) {
+        const long long items = (long long)g.M * (g.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, g);
+    }
     return yv_launch_status();
 }
 
@@ -783,6 +835,7 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!strcmp(key, "linear_variant")) { g_opt_variant = value; return YV_OK; }
     if (!strcmp(key, "linear_group_m")) { g_opt_group_m = value; return YV_OK; }
     if (!strcmp(key, "staged_epilogue")) { g_opt_staged = value; return YV_OK; }
+    if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_wide_min_n")) { g_opt_wide_min = value; return YV_OK; }
     if (!strcmp(key, "linear_wide_max_n")) { g_opt_wide_max = value; return YV_OK; }
     return YV_ERR_ARG;
@@ -846,9 +899,9 @@ extern "C" int yv_linear_ex(const void* A, int lda, const void* W, const float* 
                        (hipStream_t)stream);
 }
 
-extern "C" int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
-                         const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res,
-                         int res_ld, int flags, void* stream) {
+static int conv_impl(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
+                     const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res,
+                     int res_ld, int flags, void* ws, size_t ws_bytes, void* stream) {
     if (!in0 || !in0->ptr || !weight || !out || B <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0) return YV_ERR_ARG;
     if (!(ksize == 1 || ksize == 3) || !(stride == 1 || stride == 2)) return YV_ERR_ARG;
     if (in1 && in1->ptr && ksize != 1) return YV_ERR_ARG;
@@ -869,5 +922,34 @@ extern "C" int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout
     g.M = B * Hout * Wout; g.N = Cout; g.K = ksize * ksize * Cin;
     g.out = out; g.ldo = out_ld; g.res = (const uint16_t*)res; g.ldres = res_ld; g.flags = flags;
     g.staged = g_opt_staged && epi_can_stage(g);
+    // split-K: deep small-resolution layers (20x20 / 40x40 maps) give 100-400 tiles for 256 CUs and a serial chain of
+    // 9-36 K steps per tile at one workgroup per CU; slicing K puts >= 2 workgroups on every CU and shortens the chain
+    g.splitk = 1;
+    if (ws && g_opt_splitk) {
+        const int bn = g.N > 64 ? 128 : (g.N > 32 ? 64 : (g.N > 16 ? 32 : 16));
+        const long long tiles = (long long)((g.M + 127) / 128) * ((g.N + bn - 1) / bn);
+        const int nk = (g.K + BK - 1) / BK;
+        int S = (int)(640 / tiles);
+        if (S > nk / 2) S = nk / 2;
+        if (S > 8) S = 8;
+        if (S >= 2 && (size_t)S * g.M * g.N * sizeof(float) <= ws_bytes && !(g.N & 3)) {
+            g.splitk = S;
+            g.partial = (float*)ws;
+        }
+    }
     return dispatch<1>(g, (hipStream_t)stream);
+}
+
+extern "C" int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
+                         const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res,
+                         int res_ld, int flags, void* stream) {
+    return conv_impl(in0, in1, B, Hout, Wout, ksize, stride, weight, bias, Cout, out, out_ld, res, res_ld, flags, nullptr, 0,
+                     stream);
+}
+
+extern "C" int yv_conv2d_ws(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
+                            const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res,
+                            int res_ld, int flags, void* ws, size_t ws_bytes, void* stream) {
+    return conv_impl(in0, in1, B, Hout, Wout, ksize, stride, weight, bias, Cout, out, out_ld, res, res_ld, flags, ws, ws_bytes,
+                     stream);
 }

@@ -55,6 +55,8 @@ _SIGS = {
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "yv_conv2d": (_i, [C.POINTER(yv_view), C.POINTER(yv_view), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
                        _i, _vp]),
+    "yv_conv2d_ws": (_i, [C.POINTER(yv_view), C.POINTER(yv_view), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
+                          _i, _vp, _sz, _vp]),
     "yv_linear": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "yv_layernorm": (_i, [_vp, _sz, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _i, _vp]),
     "yv_attention": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
@@ -306,6 +308,17 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
     return out
 
 
+_CONV_WS = {}
+
+
+def _conv_workspace(device) -> torch.Tensor:
+    """Split-K partial-sum workspace (64 MB f32 per device, allocated once; launches on one stream serialise on it)."""
+    key = str(device)
+    if key not in _CONV_WS:
+        _CONV_WS[key] = torch.empty((16 * 1024 * 1024,), dtype=torch.float32, device=device)
+    return _CONV_WS[key]
+
+
 def conv2d(in0: "yv_view", in1: Optional["yv_view"], B: int, Hout: int, Wout: int, ksize: int, stride: int,
            weight: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, out_c_off: int, flags: int,
            res: Optional[torch.Tensor] = None, res_c_off: int = 0):
@@ -314,9 +327,11 @@ def conv2d(in0: "yv_view", in1: Optional["yv_view"], B: int, Hout: int, Wout: in
     esz = 4 if (flags & EPI_OUT_F32) else 2
     optr = C.c_void_p(out.data_ptr() + esz * out_c_off)
     rptr = None if res is None else C.c_void_p(res.data_ptr() + 2 * res_c_off)
-    check(lib.yv_conv2d(C.byref(in0), C.byref(in1) if in1 is not None else None, B, Hout, Wout, ksize, stride,
-                        _p(weight), _p(bias), Cout, optr, out.shape[-1], rptr,
-                        0 if res is None else res.shape[-1], flags | EPI_BIAS, _st()), "yv_conv2d")
+    ws = _conv_workspace(out.device)
+    check(lib.yv_conv2d_ws(C.byref(in0), C.byref(in1) if in1 is not None else None, B, Hout, Wout, ksize, stride,
+                           _p(weight), _p(bias), Cout, optr, out.shape[-1], rptr,
+                           0 if res is None else res.shape[-1], flags | EPI_BIAS, _p(ws), ws.numel() * 4, _st()),
+          "yv_conv2d_ws")
     return out
 
 

@@ -339,28 +339,30 @@ class VitEngine:
         self.fc2w, self.fc2b = f32(state["fc.3.weight"]), f32(state["fc.3.bias"])
         if tuple(self.fc2w.shape) != (num_classes, 128):
             raise YvError("fc.3.weight does not match num_classes")
-        self._bufs: Dict[int, dict] = {}
+        self._bufs: Dict[tuple, dict] = {}
 
-    def _buffers(self, cap: int) -> dict:
-        if cap not in self._bufs:
+    def _buffers(self, cap: int, slot: int = 0) -> dict:
+        """Activation buffers for `cap` crops; `slot` selects an independent set (concurrent sub-batches)."""
+        key = (cap, slot)
+        if key not in self._bufs:
             dev, D, N = self.dev, self.D, self.N
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
-            self._bufs[cap] = dict(
+            self._bufs[key] = dict(
                 x=z((cap * N, D), torch.float32), h=z((cap * N, D), torch.bfloat16),
                 qkv=z((cap * N, 3 * D), torch.bfloat16), o=z((cap * N, D), torch.bfloat16),
                 g=z((cap * N, 4 * D), torch.bfloat16), c=z((cap, D), torch.bfloat16),
                 feats=z((cap, 1024), torch.float32))
-        return self._bufs[cap]
+        return self._bufs[key]
 
-    def patch_buffer(self, cap: int) -> torch.Tensor:
-        b = self._buffers(cap)
+    def patch_buffer(self, cap: int, slot: int = 0) -> torch.Tensor:
+        b = self._buffers(cap, slot)
         if "pm" not in b:
             b["pm"] = torch.zeros((cap * self.tok, 3 * self.P * self.P), dtype=torch.bfloat16, device=self.dev)
         return b["pm"]
 
-    def backbone(self, patches: torch.Tensor, cap: int, count: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def backbone(self, patches: torch.Tensor, cap: int, count: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
         """patches (cap*tok, 3*P*P) bf16 -> feats (cap,1024) f32 (columns >= 1000 are zero padding)."""
-        b = self._buffers(cap)
+        b = self._buffers(cap, slot)
         D, N, tok, H = self.D, self.N, self.tok, self.H
         x, h, qkv, o, gbuf = b["x"], b["h"], b["qkv"], b["o"], b["g"]
         cls_rows(self.cls, self.pos, cap, tok, D, x)

@@ -45,32 +45,113 @@ class DetectClassifyPipeline:
         boxes, scores = self.yolo(images)
         return efficient_nms(boxes, scores, self.score_threshold, self.iou_threshold, self.topk)
 
-    def __call__(self, images: torch.Tensor, ratio: Optional[torch.Tensor] = None,
-                 dwdh: Optional[torch.Tensor] = None, img_wh: Optional[torch.Tensor] = None,
-                 src_images: Optional[torch.Tensor] = None) -> dict:
-        """images (B,S,S,3) u8 letterboxed network input; src_images (B,H,W,3) u8 originals the crops are
-        taken from (default: `images`, i.e. inputs that are already S x S: ratio 1, dwdh 0)."""
+    def detect_stage(self, images: torch.Tensor, ratio: Optional[torch.Tensor] = None,
+                     dwdh: Optional[torch.Tensor] = None, img_wh: Optional[torch.Tensor] = None) -> dict:
+        """Detector + NMS + restore/filter/dedupe/inflate + batch assembly: everything up to the crop list."""
         B, S = images.shape[0], images.shape[1]
         dev = images.device
         if ratio is None:
             c = self._identity_geometry(B, S, dev)
             ratio, dwdh, img_wh = c["ratio"], c["dwdh"], c["wh"]
-        src = images if src_images is None else src_images
         num, bb, sc, lb = self.detect(images)
         post = postprocess_dets(num, bb, sc, lb, ratio, dwdh, img_wh, self.conf, self.dedupe_iou, self.coord_mode,
                                 self.max_crops)
         per_img = self.max_crops if self.max_crops > 0 else self.topk
         cap = self.capacity if self.capacity else B * per_img
         crop_list, total = compact_crops(post["det_count"], post["crop_rect"], post["crop_ok"], cap)
+        out = dict(post)
+        out.update(num_dets=num, bboxes=bb, scores=sc, labels=lb, crop_list=crop_list, crop_total=total, capacity=cap)
+        return out
+
+    def classify_stage(self, src: torch.Tensor, det: dict, streams: Optional[Sequence[torch.cuda.Stream]] = None) -> dict:
+        """Crop gather + ViT ensemble + wrapper head for the crop list produced by detect_stage.  With `streams`
+        (2 HIP streams) the crop list is cut in two halves that run concurrently on independent buffer sets:
+        the memory-bound kernels of one half (LayerNorm, attention, residual epilogues) overlap the MFMA-bound
+        GEMMs of the other."""
+        cap, crop_list, total = det["capacity"], det["crop_list"], det["crop_total"]
+        dev = src.device
         v0 = self.vits[0]
-        patches = crop_resize_norm(src, crop_list, total, cap, v0.img, v0.P, layout=2, out=v0.patch_buffer(cap))
         logits = torch.zeros((cap, v0.nc), dtype=torch.float32, device=dev)
         labels = torch.full((cap,), -1, dtype=torch.int32, device=dev)
         w = 1.0 / len(self.vits)                      # ensemble = mean of logits (defined by this build)
-        for i, v in enumerate(self.vits):
-            feats = v.backbone(patches, cap, total)
-            v.head(feats, cap, logits, labels, scale=w, accumulate=i > 0, count=total)
-        out = dict(post)
-        out.update(num_dets=num, bboxes=bb, scores=sc, labels=lb, crop_list=crop_list, crop_total=total,
-                   cls_logits=logits, cls_label=labels, capacity=cap)
+        parts = [(0, cap, total, 0, None)]
+        if streams is not None and len(streams) >= 2 and cap >= 2:
+            half = (cap + 1) // 2
+            cnt0 = torch.clamp(total, max=half)                        # device-side scalars: no host sync
+            cnt1 = torch.clamp(total - half, min=0)
+            parts = [(0, half, cnt0, 0, streams[0]), (half, cap - half, cnt1, 1, streams[1])]
+        cur = torch.cuda.current_stream()
+        for lo, n, cnt, slot, st in parts:
+            ctx = torch.cuda.stream(st) if st is not None else _Null()
+            if st is not None:
+                st.wait_stream(cur)
+            with ctx:
+                patches = crop_resize_norm(src, crop_list[lo:lo + n], cnt, n, v0.img, v0.P, layout=2,
+                                           out=v0.patch_buffer(n, slot))
+                for i, v in enumerate(self.vits):
+                    feats = v.backbone(patches, n, cnt, slot)
+                    v.head(feats, n, logits[lo:lo + n], labels[lo:lo + n], scale=w, accumulate=i > 0, count=cnt)
+        for _, _, _, _, st in parts:
+            if st is not None:
+                cur.wait_stream(st)
+        det = dict(det)
+        det.update(cls_logits=logits, cls_label=labels)
+        return det
+
+    def __call__(self, images: torch.Tensor, ratio: Optional[torch.Tensor] = None,
+                 dwdh: Optional[torch.Tensor] = None, img_wh: Optional[torch.Tensor] = None,
+                 src_images: Optional[torch.Tensor] = None) -> dict:
+        """images (B,S,S,3) u8 letterboxed network input; src_images (B,H,W,3) u8 originals the crops are
+        taken from (default: `images`, i.e. inputs that are already S x S: ratio 1, dwdh 0)."""
+        det = self.detect_stage(images, ratio, dwdh, img_wh)
+        return self.classify_stage(images if src_images is None else src_images, det)
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class PipelinedRunner:
+    """Two-stream software pipeline over consecutive batches: while the classifier (large GEMMs that fill the
+    chip) works on batch i on one HIP stream, the detector of batch i+1 - dozens of small, latency-bound
+    kernels that leave most CUs idle - runs on a second stream in the gaps.  Every batch still passes through
+    every stage; only the schedule changes (throughput mode).  `submit()` returns the batch's result dict,
+    valid once `sync()` (or the dict's "done" event) has completed.
+
+    Hazards: the detector's activation buffers are private to the detect stream (in order); the classifier's
+    buffers are private to the classify stream; the hand-off (crop list, counts) is a fresh allocation per batch,
+    published by an event.  The classifier's patch buffer is reused every batch on ONE stream, so no extra wait
+    is needed there."""
+
+    def __init__(self, pipe: DetectClassifyPipeline, split_classifier: bool = False):
+        self.pipe = pipe
+        self.s_det = torch.cuda.Stream()
+        self.s_cls = torch.cuda.Stream()
+        self.s_sub = [torch.cuda.Stream(), torch.cuda.Stream()] if split_classifier else None
+        self._last = None
+
+    def submit(self, images: torch.Tensor, ratio=None, dwdh=None, img_wh=None, src_images=None) -> dict:
+        cur = torch.cuda.current_stream()
+        self.s_det.wait_stream(cur)                               # inputs produced on the caller's stream
+        with torch.cuda.stream(self.s_det):
+            det = self.pipe.detect_stage(images, ratio, dwdh, img_wh)
+            ready = torch.cuda.Event()
+            ready.record(self.s_det)
+        with torch.cuda.stream(self.s_cls):
+            self.s_cls.wait_event(ready)
+            out = self.pipe.classify_stage(images if src_images is None else src_images, det, self.s_sub)
+            done = torch.cuda.Event()
+            done.record(self.s_cls)
+        out["done"] = done
+        self._last = out
         return out
+
+    def sync(self):
+        self.s_det.synchronize()
+        self.s_cls.synchronize()
+        for st in (self.s_sub or []):
+            st.synchronize()
