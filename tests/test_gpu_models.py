@@ -104,3 +104,32 @@ def test_pipelined_runner_matches_single_stream():
             assert o["done"].query()
             for k in keys:
                 assert torch.equal(o[k], r[k]), (split, k)
+
+
+def test_pipeline_with_zero_detections():
+    """No candidate above the score threshold: every later stage sees an empty batch (device-side count 0)."""
+    from yvhip import engines
+    from yvhip.pipeline import DetectClassifyPipeline
+    name, S, B = "vit_tiny_test", 64, 2
+    ysd = engines.init_yolo_state("n", 5, 3, 1.0, cls_bias=-30.0)
+    pipe = DetectClassifyPipeline(engines.YoloEngine(ysd, "n", 5, S, DEV),
+                                  [engines.VitEngine(engines.init_vit_wrapper_state(name, 5, 4), name, 5, device=DEV)])
+    img = torch.zeros(B, S, S, 3, dtype=torch.uint8, device=DEV)
+    out = pipe(img)
+    torch.cuda.synchronize()
+    assert out["num_dets"].cpu().tolist() == [[0], [0]] and int(out["crop_total"][0]) == 0
+    assert out["det_count"].cpu().tolist() == [0, 0]
+    assert torch.all(out["cls_label"] == -1) and float(out["cls_logits"].abs().sum()) == 0
+
+
+def test_vit_large_engine_shapes():
+    """ViT-L/16 (BASELINE configs[4] classifier): D = 1024, 16 heads, 24 blocks through the same kernels."""
+    from yvhip import engines
+    sd = engines.init_vit_wrapper_state("vit_large_patch16_224", 5, seed=1)
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("model.")) == 304326632
+    eng = engines.VitEngine(sd, "vit_large_patch16_224", 5)
+    g = torch.Generator().manual_seed(0)
+    pm = (torch.rand(2 * 196, 768, generator=g) * 2 - 1).to(torch.bfloat16).to(DEV)
+    feats = eng.backbone(pm, 2)
+    torch.cuda.synchronize()
+    assert feats.shape == (2, 1024) and bool(torch.isfinite(feats).all()) and float(feats[:, :1000].abs().sum()) > 0

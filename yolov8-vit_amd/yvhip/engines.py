@@ -262,6 +262,7 @@ class YoloEngine:
 VIT_CFGS = {
     "vit_base_patch16_224": (16, 768, 12, 12),
     "vit_base_patch8_224": (8, 768, 12, 12),            # the reference's configured model (utils/class_config.py:21)
+    "vit_large_patch16_224": (16, 1024, 24, 16),        # BASELINE.json configs[4]
     "vit_large_patch16_224": (16, 1024, 24, 16),
     "vit_tiny_test": (16, 128, 2, 2),
     "vit_tiny8_test": (8, 128, 2, 2),
