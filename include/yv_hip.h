@@ -41,6 +41,9 @@ int yv_device_is_gfx950(void);
 /* Tuning knobs (process-wide, not part of the reference surface): "linear_variant" (0 register-staged
  * 128x128, 1 LDS-DMA 128x128, 2 256x128, 3 256x256, 4 128x256), "linear_group_m" (M tiles per L2 group). */
 int yv_set_option(const char* key, int value);
+/* Registers (ws != NULL) or removes a caller-owned f32 scratch buffer for split-K partial sums used by launches
+ * on `stream`.  One buffer per stream: launches of a stream are ordered, different streams must not share one. */
+int yv_set_workspace(void* stream, void* ws, size_t bytes);
 
 /* ------------------------------------------------------------------ boxes */
 

@@ -19,6 +19,8 @@
 //   blockIdx is remapped so that the 8 XCDs each walk contiguous N tiles of the same
 //   M tile (activation rows stay in that XCD's L2).
 #include <string.h>
+#include <map>
+#include <mutex>
 #include "yv_common.h"
 
 namespace {
@@ -27,6 +29,16 @@ constexpr int BK = 64;            // bf16 elements per K step
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
 int g_opt_group_m = 8;
 int g_opt_staged = 1;
+std::mutex g_ws_mu;
+std::map<void*, std::pair<void*, size_t>> g_ws;   // per-stream split-K workspace (yv_set_workspace)
+static bool ws_lookup(void* stream, void** ws, size_t* bytes) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_ws.find(stream);
+    if (it == g_ws.end()) return false;
+    *ws = it->second.first; *bytes = it->second.second;
+    return true;
+}
+int g_opt_linear_splitk = 1;
 int g_opt_splitk = 0;           // measured neutral end-to-end (tools/e2e_ab.py): the reduce pass costs what the shorter chain saves
 int g_opt_wide_min = 1 << 30, g_opt_wide_max = 1 << 30; // N range that takes the 8-phase 256x256 kernel (off by
                                                           // default: end-to-end A/B, tools/e2e_ab.py, favours 128x128)
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
     }
 
     if (S > 1) {                               // raw partial sums; bias / activation happen in splitk_reduce_kernel
-        float* P = g.partial + (long long)slice * M * g.N;
+        float* P = g.partial + (long long)slice * g.M * g.N;
 #pragma unroll
         for (int j = 0; j < MF; ++j) {
             const int m = m0 + wrow_m + j * 16 + fr;
@@ -507,6 +519,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
     }
+    // split-K (wgrad-shaped problems: few output tiles, long K): slices of one tile are neighbouring workgroups
+    const int S = g.splitk > 1 ? g.splitk : 1;
+    const int slice = bid % S;
+    bid /= S;
     // grouped order inside the XCD's chunk: GM consecutive M tiles share each W tile while it is hot in L2
     int tm, tn;
     {
@@ -558,12 +574,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
     const int wrow_m = wm * (BM / WM), wrow_n = wn * (BN / WN);
     const int fr = lane & 15, fq = lane >> 4;
 
-    const int nk = g.K / BK;
-    issue(0, 0);
+    const int nk_all = g.K / BK;
+    const int kt0 = (int)((long long)nk_all * slice / S), nk = (int)((long long)nk_all * (slice + 1) / S);
+    issue(kt0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         if (ABL != 1 && kt + 1 < nk) issue(kt + 1, cur ^ 1);
         const unsigned char* A = smem + cur * (A_BYTES + W_BYTES);
         const unsigned char* W = A + A_BYTES;
@@ -592,6 +609,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    if (S > 1) {                               // raw partial sums; the epilogue runs in splitk_reduce_kernel
+        float* P = g.partial + (long long)slice * g.M * g.N;
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int m = m0 + wrow_m + j * 16 + fr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int n = n0 + wrow_n + i * 16 + fq * 4;
+                if (n < g.N) *(float4*)(P + (long long)m * g.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
     }
     if (ABL != 4) finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
     else if (acc[0][0][0] == 12345.678f) finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
@@ -786,7 +817,12 @@ int launch_dma(GemmArgs& g, hipStream_t st) {
     if (lds > 65536 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
+    const int S = g.splitk > 1 ? g.splitk : 1;
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * S), dim3(WM * WN * 64), lds, st, g);
+    if (S > 1) {
+        const long long items = (long long)g.M * (g.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, g);
+    }
     return yv_launch_status();
 }
 
@@ -830,12 +866,20 @@ int dispatch(GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int yv_set_workspace(void* stream, void* ws, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (!ws || !bytes) g_ws.erase(stream);
+    else g_ws[stream] = std::make_pair(ws, bytes);
+    return YV_OK;
+}
+
 extern "C" int yv_set_option(const char* key, int value) {
     if (!key) return YV_ERR_ARG;
     if (!strcmp(key, "linear_variant")) { g_opt_variant = value; return YV_OK; }
     if (!strcmp(key, "linear_group_m")) { g_opt_group_m = value; return YV_OK; }
     if (!strcmp(key, "staged_epilogue")) { g_opt_staged = value; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
+    if (!strcmp(key, "linear_splitk")) { g_opt_linear_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_wide_min_n")) { g_opt_wide_min = value; return YV_OK; }
     if (!strcmp(key, "linear_wide_max_n")) { g_opt_wide_max = value; return YV_OK; }
     return YV_ERR_ARG;
@@ -862,8 +906,22 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
     if ((flags & (YV_EPI_SAVE_PRE | YV_EPI_GELU_BWD)) && (!g.staged || (K % BK) || N <= 64)) return YV_ERR_ARG;
     if (res_f32 && (!g.staged || (K % BK) || N <= 64)) return YV_ERR_ARG;
     g.group_m = g_opt_group_m > 0 ? g_opt_group_m : 8;
+    g.splitk = 1;
     if ((K % BK) == 0 && N > 64 && g_opt_variant != 0) {
+        // split-K for wgrad-shaped problems (few 128x128 output tiles, long reduction): a 2304x768 weight gradient
+        // over 6336 tokens is 108 tiles for 256 CUs; slicing K fills the chip.  Deterministic: partial sums go to
+        // the stream's workspace and are added in slice order by splitk_reduce_kernel.
+        void* ws = nullptr; size_t wsb = 0;
+        if (g_opt_linear_splitk && !(flags & ~(YV_EPI_BIAS | YV_EPI_OUT_F32)) && !m_dev && ws_lookup((void*)stream, &ws, &wsb)) {
+            const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+            const int nk = K / BK;
+            int S = (int)(768 / tiles);
+            if (S > nk / 4) S = nk / 4;
+            if (S > 8) S = 8;
+            if (S >= 2 && (size_t)S * M * N * sizeof(float) <= wsb) { g.splitk = S; g.partial = (float*)ws; }
+        }
         int variant = g_opt_variant;
+        if (g.splitk > 1) variant = 10;
         // auto: 128x128 tiles, two workgroups per CU (one workgroup's epilogue overlaps the other's main loop).
         // Isolated, the 8-phase 256x256 kernel is 3-13 % faster on N >= 1536, but inside the pipeline (operands
         // cold in L2, GELU / residual epilogues) the interleaved end-to-end A/B measures it 1-2 % slower.

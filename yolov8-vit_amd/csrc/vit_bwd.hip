@@ -267,15 +267,17 @@ extern "C" int yv_cast_weights(const float* w, int N, int K, void* w_bf16, void*
     return yv_launch_status();
 }
 
-extern "C" size_t yv_colsum_ws_floats(int rows, int cols) { return (size_t)((rows + 255) / 256) * (size_t)cols; }
+constexpr int CS_ROWS = 32;         // rows per workgroup of the column-sum kernels (6304 rows -> 197 x cols/256 workgroups)
+
+extern "C" size_t yv_colsum_ws_floats(int rows, int cols) { return (size_t)((rows + CS_ROWS - 1) / CS_ROWS) * (size_t)cols; }
 
 extern "C" int yv_cast_colsum(const float* x, int rows, int cols, void* y_bf16, float* colsum, int accumulate,
                               float* ws, void* stream) {
     if (!x || rows <= 0 || cols <= 0 || (colsum && !ws)) return YV_ERR_ARG;
-    const int parts = (rows + 255) / 256;
+    const int parts = (rows + CS_ROWS - 1) / CS_ROWS;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(cast_colsum_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, x, rows, cols,
-                       (uint16_t*)y_bf16, colsum ? ws : nullptr, 256);
+                       (uint16_t*)y_bf16, colsum ? ws : nullptr, CS_ROWS);
     if (colsum)
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, ws, parts, cols, colsum,
                            accumulate);
@@ -285,10 +287,10 @@ extern "C" int yv_cast_colsum(const float* x, int rows, int cols, void* y_bf16, 
 extern "C" int yv_colsum_bf16(const void* x, int rows, int cols, long long ld, float* colsum, int accumulate, float* ws,
                               void* stream) {
     if (!x || !colsum || !ws || rows <= 0 || cols <= 0) return YV_ERR_ARG;
-    const int parts = (rows + 255) / 256;
+    const int parts = (rows + CS_ROWS - 1) / CS_ROWS;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, (const uint16_t*)x, rows,
-                       cols, ld, ws, 256);
+                       cols, ld, ws, CS_ROWS);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, ws, parts, cols, colsum,
                        accumulate);
     return yv_launch_status();

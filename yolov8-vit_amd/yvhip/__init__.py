@@ -44,6 +44,7 @@ _SIGS = {
     "yv_error_string": (C.c_char_p, [_i]),
     "yv_device_is_gfx950": (_i, []),
     "yv_set_option": (_i, [C.c_char_p, _i]),
+    "yv_set_workspace": (_i, [_vp, _vp, _sz]),
     "yv_custom_nms_ws_bytes": (_sz, [_i, _i]),
     "yv_custom_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "yv_efficient_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -123,8 +124,18 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_STREAM_WS = {}
+
+
 def _st():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Current HIP stream handle; the first use of a stream registers its split-K workspace (64 MB)."""
+    h = torch.cuda.current_stream().cuda_stream
+    key = (torch.cuda.current_device(), h)
+    if key not in _STREAM_WS:
+        ws = torch.empty((16 * 1024 * 1024,), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+        _STREAM_WS[key] = ws
+        lib.yv_set_workspace(C.c_void_p(h), C.c_void_p(ws.data_ptr()), ws.numel() * 4)
+    return C.c_void_p(h)
 
 
 def _chk_dev(*ts):
