@@ -69,11 +69,22 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
 
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int parts, int cols,
                                                           float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    // 32 columns x 8 row-groups per workgroup; each group sums every 8th partial row (fixed order), then the 8 group
+    // sums are added in group order: deterministic, and 8x the parallelism of one thread per column
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int p = 0; p < parts; ++p) s += partial[(long long)p * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < cols)
+        for (int p = grp; p < parts; p += 8) s += partial[(long long)p * cols + c];
+    red[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && c < cols) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += red[q][cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------- LayerNorm backward
@@ -279,7 +290,7 @@ extern "C" int yv_cast_colsum(const float* x, int rows, int cols, void* y_bf16, 
     hipLaunchKernelGGL(cast_colsum_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, x, rows, cols,
                        (uint16_t*)y_bf16, colsum ? ws : nullptr, CS_ROWS);
     if (colsum)
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, ws, parts, cols, colsum,
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, ws, parts, cols, colsum,
                            accumulate);
     return yv_launch_status();
 }
@@ -291,7 +302,7 @@ extern "C" int yv_colsum_bf16(const void* x, int rows, int cols, long long ld, f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, (const uint16_t*)x, rows,
                        cols, ld, ws, CS_ROWS);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, ws, parts, cols, colsum,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, ws, parts, cols, colsum,
                        accumulate);
     return yv_launch_status();
 }
@@ -312,7 +323,7 @@ extern "C" int yv_layernorm_bwd(const float* x, long long ldx, const float* gamm
                        rows, D, eps, dx, lddx, ws);
     // partial layout [block][2][D]: reduce with stride 2*D -> view as `blocks` rows of 2*D columns
     float* tmp = ws + (size_t)blocks * 2 * D;          // the last 2*D floats of the workspace
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, ws, blocks, 2 * D, tmp, 0);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, st, ws, blocks, 2 * D, tmp, 0);
     (void)hipMemcpyAsync(dgamma, tmp, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(dbeta, tmp + D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
     return yv_launch_status();
