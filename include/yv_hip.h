@@ -209,6 +209,11 @@ int yv_attention_train(const void* qkv, int R, int N, int H, float scale, void* 
 int yv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int R, int N, int H,
                      float scale, void* dqkv, float* delta_ws, void* stream);
 
+/* Weight gradient dW (N,K) f32 = dY^T . X with dY (T,N) and X (T,K) bf16 token-major (T = tokens, a multiple of 64
+ * whose tail rows are ZERO): the fragments are columns of the LDS tiles, read with ds_read_b64_tr_b16; no transposed
+ * copies.  Split over T when a workspace is registered for the stream (deterministic). */
+int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, int N, int K, float* dW, int ldw, void* stream);
+
 /* out_t[c][r] = in[r][c] (bf16), rows of out_t zero padded up to the next multiple of 64 (ld_out >= that). */
 int yv_transpose_bf16(const void* in, int rows, int cols, long long ld_in, void* out_t, long long ld_out, void* stream);
 

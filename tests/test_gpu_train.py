@@ -189,3 +189,23 @@ def test_trainer_two_steps_follow_sgd(yv):
         d_ref = params[k] - sd[k]
         d_got = new[k].cpu() - sd[k]
         assert rel_l2(d_got, d_ref) < 1.2e-1, k            # two accumulated bf16-noise gradients (see the table tool)
+
+
+@pytest.mark.parametrize("T,N,K", [(64, 128, 128), (6336, 2304, 768), (448, 1000, 768), (640, 768, 3072), (128, 72, 200)])
+def test_wgrad_transposing_gemm(yv, T, N, K):
+    """dW = dY^T . X with hardware-transposed LDS reads: small-integer operands make the f32 result EXACT, so a
+    wrong lane map / swizzle / token order cannot hide behind a tolerance; asymmetric operands catch transposes."""
+    g = torch.Generator().manual_seed(T + N)
+    live = T - 37 if T > 64 else T                                   # zero-padded tail rows
+    dy = torch.zeros(T, N); dy[:live] = torch.randint(-3, 4, (live, N), generator=g).float()
+    x = torch.zeros(T, K); x[:live] = torch.randint(-2, 3, (live, K), generator=g).float()
+    ref = dy.t() @ x
+    dw = torch.full((N, K), 7.0, device=DEV)
+    yv.wgrad(dy.to(torch.bfloat16).to(DEV), x.to(torch.bfloat16).to(DEV), dw)
+    assert torch.equal(dw.cpu(), ref)
+    # column-sliced dY (the backbone-head gradient uses the first 1000 of 1024 columns)
+    if N == 1000:
+        dyp = torch.zeros(T, 1024, dtype=torch.bfloat16); dyp[:, :1000] = dy.to(torch.bfloat16)
+        dw2 = torch.zeros(N, K, device=DEV)
+        yv.wgrad(dyp.to(DEV)[:, :1000], x.to(torch.bfloat16).to(DEV), dw2)
+        assert torch.equal(dw2.cpu(), ref)

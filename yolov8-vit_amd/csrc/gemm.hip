@@ -808,6 +808,126 @@ int launch_8phase(GemmArgs& g, hipStream_t st) {
     return yv_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient GEMM ("TN"): dW[n][k] = sum_t dY[t][n] * X[t][k], t = token (the reduction index).
+// Both operands are stored token-major, i.e. the reduction index is the ROW of the LDS tiles, so the MFMA
+// fragments (8 consecutive reduction elements per lane) are COLUMNS of those tiles: they are read with the
+// gfx950 hardware-transposing LDS read ds_read_b64_tr_b16 (two reads per fragment), and no transposed copy of
+// the activations or of the incoming gradient is ever materialised.
+//   tiles: [64 tokens][128 columns] bf16 = 256-byte LDS rows, filled by LDS-DMA (4 rows per wave-instruction);
+//   the 16-byte chunk index is XOR-swizzled with ((row&3)<<1 | ((row>>3)&1)<<3) on the SOURCE address and on the
+//   read, which spreads the 4 rows x 4 chunks a 16-lane group touches (and the two groups of a 32-lane half)
+//   over distinct banks.
+//   MFMA A operand = X columns (rows of the result = k), B operand = dY columns (result columns = n), so a lane
+//   owns 4 consecutive k of one n: 16-byte f32 stores into dW (n, k).
+// Token rows must be padded with ZERO rows up to a multiple of 64 (the trainer allocates its activations so).
+// Few output tiles, long reduction -> always split over the token dimension (deterministic slice-order reduce).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
+    // g.a0 = dY (T, N) ld lda0 ; g.w = X (T, K) ld lda1 ; T = g.K (multiple of 64) ; out (N, K) f32 ld ldo
+    constexpr int TB = 64, TILE = TB * 256;                   // bytes per operand tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Nw = g.M, Kw = g.N, T = g.K;
+    int bid = blockIdx.x;
+    const int S = g.splitk > 1 ? g.splitk : 1;
+    const int slice = bid % S;
+    bid /= S;
+    const int tn_ = bid / g.tiles_n, tk_ = bid - tn_ * g.tiles_n;
+    const int n0 = tn_ * 128, k0 = tk_ * 128;
+
+    // DMA: lane -> (row = 4*instr + lane/16, chunk' = lane%16); source chunk = chunk' ^ swz(row)
+    const int lr = lane >> 4, lc = lane & 15;
+    const uint16_t* ysrc[4];
+    const uint16_t* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (j * 4 + wave) * 4 + lr;              // 0..63
+        const int ch = lc ^ tn_swz(row);
+        int cn = n0 + ch * 8; cn = cn < Nw ? cn : Nw - 8;      // column clamp (results of clamped columns are not stored)
+        int ck = k0 + ch * 8; ck = ck < Kw ? ck : Kw - 8;
+        ysrc[j] = g.a0 + (long long)row * g.lda0 + cn;
+        xsrc[j] = g.w + (long long)row * g.lda1 + ck;
+    }
+    auto issue = [&](int tt, int buf) {
+        unsigned char* Yt = smem + buf * (2 * TILE);
+        unsigned char* Xt = Yt + TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ysrc[j] + (long long)tt * TB * g.lda0), (lptr_t)(Yt + (j * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + (long long)tt * TB * g.lda1), (lptr_t)(Xt + (j * 4 + wave) * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];                                          // [k fragment][n fragment]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wk = wave >> 1, wn = wave & 1;                  // 2 x 2 waves, 64 (k) x 64 (n) each
+    const int fi = lane & 15, mg = lane >> 4;
+    const int q = fi >> 2, p = fi & 3;                        // address role inside the 16-lane group
+
+    // transposed fragment: 8 consecutive tokens (32*ks + 8*mg + 0..7) of column col0 + fi, from a [64][128] tile
+    auto frag = [&](const unsigned char* tile, int ks, int col0) -> bf16x8 {
+        const int row = ks * 32 + mg * 8 + q;
+        const int ch = ((col0 + 4 * p) >> 3);
+        const int off = ((col0 + 4 * p) & 7) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + row * 256 + ((ch ^ tn_swz(row)) << 4) + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + (row + 4) * 256 + ((ch ^ tn_swz(row + 4)) << 4) + off));
+        const u32x4 pk = {__builtin_bit_cast(u32x2, lo)[0], __builtin_bit_cast(u32x2, lo)[1],
+                          __builtin_bit_cast(u32x2, hi)[0], __builtin_bit_cast(u32x2, hi)[1]};
+        return __builtin_bit_cast(bf16x8, pk);
+    };
+
+    const int nt_all = T / TB;
+    const int t0 = (int)((long long)nt_all * slice / S), t1 = (int)((long long)nt_all * (slice + 1) / S);
+    if (t0 < t1) {
+        issue(t0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int tt = t0; tt < t1; ++tt) {
+        const int cur = (tt - t0) & 1;
+        if (tt + 1 < t1) issue(tt + 1, cur ^ 1);
+        const unsigned char* Yt = smem + cur * (2 * TILE);
+        const unsigned char* Xt = Yt + TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fx[4], fy[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fx[i] = frag(Xt, ks, wk * 64 + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fy[j] = frag(Yt, ks, wn * 64 + j * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fy[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // D[row = k (lane>>4)*4 + reg][col = n (lane&15)]  ->  dW[n][k..k+3]
+    float* out = S > 1 ? g.partial + (long long)slice * Nw * Kw : (float*)g.out;
+    const long long ldo = S > 1 ? Kw : g.ldo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + fi;
+        if (n >= Nw) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + wk * 64 + i * 16 + mg * 4;
+            if (k < Kw) *(float4*)(out + (long long)n * ldo + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int ABL = 0>
 int launch_dma(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
@@ -996,6 +1116,34 @@ static int conv_impl(const yv_view* in0, const yv_view* in1, int B, int Hout, in
         }
     }
     return dispatch<1>(g, (hipStream_t)stream);
+}
+
+extern "C" int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, int N, int K, float* dW, int ldw,
+                        void* stream) {
+    if (!dY || !X || !dW || T <= 0 || N <= 0 || K <= 0) return YV_ERR_ARG;
+    if ((T & 63) || (N & 7) || (K & 7) || (ldy & 7) || (ldx & 7) || (ldw & 3)) return YV_ERR_ARG;
+    if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW) & 15) return YV_ERR_ARG;
+    GemmArgs g = {};
+    g.a0 = (const uint16_t*)dY; g.lda0 = ldy; g.w = (const uint16_t*)X; g.lda1 = ldx;
+    g.M = N; g.N = K; g.K = T; g.out = dW; g.ldo = ldw; g.flags = YV_EPI_OUT_F32;
+    g.tiles_m = (N + 127) / 128; g.tiles_n = (K + 127) / 128;
+    void* ws = nullptr; size_t wsb = 0;
+    g.splitk = 1;
+    if (ws_lookup(stream, &ws, &wsb)) {
+        const long long tiles = (long long)g.tiles_m * g.tiles_n;
+        int S = (int)(1024 / tiles);
+        if (S > T / 64 / 2) S = T / 64 / 2;
+        if (S > 16) S = 16;
+        if (S >= 2 && (size_t)S * N * K * sizeof(float) <= wsb) { g.splitk = S; g.partial = (float*)ws; }
+    }
+    const int S = g.splitk;
+    const size_t lds = 2 * 2 * 64 * 256;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(g.tiles_m * g.tiles_n * S), dim3(256), lds, (hipStream_t)stream, g);
+    if (S > 1) {
+        const long long items = (long long)g.M * (g.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g);
+    }
+    return yv_launch_status();
 }
 
 extern "C" int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,

@@ -68,6 +68,7 @@ _SIGS = {
     "yv_linear_ex": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "yv_attention_train": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "yv_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "yv_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "yv_transpose_bf16": (_i, [_vp, _i, _i, C.c_longlong, _vp, C.c_longlong, _vp]),
     "yv_cast_weights": (_i, [_vp, _i, _i, _vp, _vp, C.c_longlong, _vp]),
     "yv_colsum_ws_floats": (_sz, [_i, _i]),
@@ -448,3 +449,14 @@ def token_reduce(dx, R, N, D, out):
 def head_bwd(feats, w1t, b1, w2, dlogits, R, nc, dw1, db1, dw2, db2, dfeats, ws):
     check(lib.yv_head_bwd(_p(feats), feats.stride(0), _p(w1t), _p(b1), _p(w2), _p(dlogits), R, nc, _p(dw1), _p(db1),
                           _p(dw2), _p(db2), _p(dfeats), dfeats.stride(0), _p(ws), _st()), "yv_head_bwd")
+
+
+def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, T: Optional[int] = None):
+    """dw (N,K) f32 = dy[:T]^T @ x[:T]; dy (>=T,N), x (>=T,K) bf16, T a multiple of 64 with zero tail rows."""
+    for t_ in (dy, x, dw):
+        if not t_.is_cuda or t_.stride(-1) != 1:
+            raise YvError("wgrad operands must be device tensors with unit column stride")
+    t = dy.shape[0] if T is None else T
+    check(lib.yv_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), t, dy.shape[1], x.shape[1], _p(dw), dw.stride(0), _st()),
+          "yv_wgrad")
+    return dw

@@ -21,7 +21,7 @@ import torch
 
 from . import (EPI_GELU, EPI_GELU_BWD, EPI_OUT_F32, EPI_POSEMB, EPI_RES_F32, EPI_SAVE_PRE, YvError, attention_bwd,
                attention_train, cast_colsum, cast_weights, cls_rows, colsum_bf16, head_bwd, layernorm, layernorm_bwd, lib,
-               linear, linear_ex, loss_fwd_bwd, require_gpu, sgd_step, token_reduce, transpose_bf16, wrapper_head)
+               linear, linear_ex, loss_fwd_bwd, require_gpu, sgd_step, token_reduce, wgrad, wrapper_head)
 from .engines import vit_cfg
 
 
@@ -108,17 +108,25 @@ class VitTrainer:
         M, Mp = R * N, _r64(R * N)
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
         b16 = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=dev)
-        b = dict(M=M, Mp=Mp,
+        Rp, Tp = _r64(R), _r64(R * self.tok)
+        # operands of a weight gradient are allocated with their token dimension padded to 64 ZERO rows (never
+        # written: every producer stops at row M); "*_full" is the padded tensor, the plain name its [:M] view
+        pad = lambda rows, rp, cols: b16(rp, cols)
+        full = dict(h1=[pad(M, Mp, D) for _ in range(L)], o=[pad(M, Mp, D) for _ in range(L)],
+                    h2=[pad(M, Mp, D) for _ in range(L)], g=[pad(M, Mp, 4 * D) for _ in range(L)],
+                    dxb=pad(M, Mp, D), dwide=pad(M, Mp, 4 * D), dqkv=pad(M, Mp, 3 * D),
+                    dfeats=pad(R, Rp, 1024), c=pad(R, Rp, D), dtok=pad(R * self.tok, Tp, D),
+                    patches=pad(R * self.tok, Tp, 3 * self.P_ * self.P_))
+        b = dict(M=M, Mp=Mp, Rp=Rp, Tp=Tp, full=full,
                  x=[f32(M, D) for _ in range(2 * L + 1)],                      # residual stream snapshots
-                 h1=[b16(M, D) for _ in range(L)], qkv=[b16(M, 3 * D) for _ in range(L)],
-                 o=[b16(M, D) for _ in range(L)], lse=[f32(R * self.H * N) for _ in range(L)],
-                 h2=[b16(M, D) for _ in range(L)], u=[b16(M, 4 * D) for _ in range(L)], g=[b16(M, 4 * D) for _ in range(L)],
-                 c=b16(R, D), feats=f32(R, 1024), logits=f32(R, self.nc), labels=torch.zeros(R, dtype=torch.int32, device=dev),
-                 dx=f32(M, D), dxb=b16(M, D), dwide=b16(M, 4 * D), dqkv=b16(M, 3 * D), dnar=b16(M, D),
-                 xt=b16(4 * D, Mp), dyt=b16(4 * D, Mp), delta=f32(R * self.H * N),
-                 dfeats=b16(R, 1024), dc=b16(R, D), ct=b16(D, _r64(R)), dft=b16(1024, _r64(R)),
-                 dtok=b16(R * self.tok, D), dtok32=f32(R * self.tok, D), ptok_t=b16(3 * self.P_ * self.P_, _r64(R * self.tok)),
-                 dtok_t=b16(D, _r64(R * self.tok)), dpos=f32(N, D),
+                 h1=[t[:M] for t in full["h1"]], qkv=[b16(M, 3 * D) for _ in range(L)],
+                 o=[t[:M] for t in full["o"]], lse=[f32(R * self.H * N) for _ in range(L)],
+                 h2=[t[:M] for t in full["h2"]], u=[b16(M, 4 * D) for _ in range(L)], g=[t[:M] for t in full["g"]],
+                 c=full["c"][:R], feats=f32(R, 1024), logits=f32(R, self.nc), labels=torch.zeros(R, dtype=torch.int32, device=dev),
+                 dx=f32(M, D), dxb=full["dxb"][:M], dwide=full["dwide"][:M], dqkv=full["dqkv"][:M], dnar=b16(M, D),
+                 delta=f32(R * self.H * N), dfeats=full["dfeats"][:R], dc=b16(R, D),
+                 dtok=full["dtok"][:R * self.tok], dtok32=f32(R * self.tok, D), patches=full["patches"][:R * self.tok],
+                 dpos=f32(N, D),
                  ws=f32(max(int(lib.yv_colsum_ws_floats(M, 4 * D)), int(lib.yv_layernorm_bwd_ws_floats(M, D)), 2 * R * 128) + 64))
         self._bufs[R] = b
         return b
@@ -129,6 +137,8 @@ class VitTrainer:
         D, N, tok, H, L = self.D, self.N, self.tok, self.H, self.L
         M = R * N
         W = lambda k: self.gemm_w[k][2]
+        b["patches"].copy_(patches)                            # token-padded copy (operand of the patch-embed wgrad)
+        patches = b["patches"]
         x0 = b["x"][0]
         cls_rows(self.p("model.cls_token").reshape(D), self.p("model.pos_embed").reshape(N, D), R, tok, D, x0)
         linear(patches, W("model.patch_embed.proj.weight"), self.p("model.patch_embed.proj.bias"), x0,
@@ -154,17 +164,10 @@ class VitTrainer:
         return b["logits"]
 
     # ---- backward ---------------------------------------------------------------------------------------
-    def _wgrad(self, key: str, dy: torch.Tensor, x: torch.Tensor, rows: int, b: dict, dyt=None, xt=None):
-        """G[key] (N,K) = dy^T (N,rows) . x (rows,K): both operands transposed to token-major, MFMA GEMM."""
+    def _wgrad(self, key: str, dy_full: torch.Tensor, x_full: torch.Tensor):
+        """G[key] (N,K) = dy^T . x over the (64-padded, zero-tailed) token rows: transposing-read MFMA GEMM."""
         N, K = self.gemm_w[key][0], self.gemm_w[key][1]
-        rp = _r64(rows)
-        dyt = b["dyt"] if dyt is None else dyt
-        xt = b["xt"] if xt is None else xt
-        dyt_v = dyt.view(-1)[: dy.shape[1] * rp].view(dy.shape[1], rp)
-        xt_v = xt.view(-1)[: x.shape[1] * rp].view(x.shape[1], rp)
-        transpose_bf16(dy, dyt_v, rows)
-        transpose_bf16(x, xt_v, rows)
-        linear(dyt_v, xt_v, None, self.g(key).reshape(N, K), flags=EPI_OUT_F32, M=N)
+        wgrad(dy_full, x_full, self.g(key).reshape(N, K))
 
     def _launch_ready_buckets(self, low_offset: int):
         """Gradients at offsets >= low_offset are final: start their all-reduce while backward continues."""
@@ -183,7 +186,7 @@ class VitTrainer:
         self._launch_ready_buckets(self.off["fc.1.weight"])
         colsum_bf16(b["dfeats"], b["ws"][:1024], b["ws"][1024:], rows=R)
         self.g("model.head.bias").copy_(b["ws"][:1000])
-        self._wgrad("model.head.weight", b["dfeats"], b["c"], R, b, dyt=b["dft"], xt=b["ct"])
+        self._wgrad("model.head.weight", b["full"]["dfeats"][:, :1000], b["full"]["c"])
         linear(b["dfeats"], Wt("model.head.weight"), None, b["dc"])
         b["dx"].zero_()
         layernorm_bwd(b["x"][2 * L], N * D, self.p("model.norm.weight"), b["dc"], D, R, D, b["dx"], N * D,
@@ -196,20 +199,20 @@ class VitTrainer:
             dx, dxb = b["dx"], b["dxb"]
             # MLP branch
             cast_colsum(dx, dxb, self.g(k + "mlp.fc2.bias"), b["ws"])
-            self._wgrad(k + "mlp.fc2.weight", dxb, b["g"][i], M, b)
+            self._wgrad(k + "mlp.fc2.weight", b["full"]["dxb"], b["full"]["g"][i])
             linear_ex(dxb, Wt(k + "mlp.fc2.weight"), None, b["dwide"], flags=EPI_GELU_BWD, aux=b["u"][i])
             colsum_bf16(b["dwide"], self.g(k + "mlp.fc1.bias"), b["ws"])
-            self._wgrad(k + "mlp.fc1.weight", b["dwide"], b["h2"][i], M, b)
+            self._wgrad(k + "mlp.fc1.weight", b["full"]["dwide"], b["full"]["h2"][i])
             linear(b["dwide"], Wt(k + "mlp.fc1.weight"), None, b["dnar"])
             layernorm_bwd(xmid, D, self.p(k + "norm2.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm2.weight"), self.g(k + "norm2.bias"), b["ws"])
             # attention branch
             cast_colsum(dx, dxb, self.g(k + "attn.proj.bias"), b["ws"])
-            self._wgrad(k + "attn.proj.weight", dxb, b["o"][i], M, b)
+            self._wgrad(k + "attn.proj.weight", b["full"]["dxb"], b["full"]["o"][i])
             linear(dxb, Wt(k + "attn.proj.weight"), None, b["dnar"])
             attention_bwd(b["qkv"][i], b["o"][i], b["dnar"], b["lse"][i], R, N, H, b["dqkv"], b["delta"])
             colsum_bf16(b["dqkv"], self.g(k + "attn.qkv.bias"), b["ws"])
-            self._wgrad(k + "attn.qkv.weight", b["dqkv"], b["h1"][i], M, b)
+            self._wgrad(k + "attn.qkv.weight", b["full"]["dqkv"], b["full"]["h1"][i])
             linear(b["dqkv"], Wt(k + "attn.qkv.weight"), None, b["dnar"])
             layernorm_bwd(xin, D, self.p(k + "norm1.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm1.weight"), self.g(k + "norm1.bias"), b["ws"])
@@ -220,7 +223,7 @@ class VitTrainer:
         self.g("model.cls_token").copy_(b["dpos"][0].view(1, 1, D))
         b["dtok32"].copy_(b["dx"].view(R, N, D)[:, 1:, :].reshape(R * tok, D))          # drop the cls rows (copy only)
         cast_colsum(b["dtok32"], b["dtok"], self.g("model.patch_embed.proj.bias"), b["ws"])
-        self._wgrad("model.patch_embed.proj.weight", b["dtok"], patches, R * tok, b, dyt=b["dtok_t"], xt=b["ptok_t"])
+        self._wgrad("model.patch_embed.proj.weight", b["full"]["dtok"], b["full"]["patches"])
         return loss
 
     # ---- optimizer ----------------------------------------------------------------------------------------
