@@ -209,6 +209,12 @@ int yv_attention_train(const void* qkv, int R, int N, int H, float scale, void* 
 int yv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int R, int N, int H,
                      float scale, void* dqkv, float* delta_ws, void* stream);
 
+/* out[M,N] (bf16) = A[M,K] . Wkn[K,N] with the weight in reduction-major layout (row stride ldw): the data
+ * gradient dX = dY . W reads the (N_w, K_w) weight as it is stored, through transposing LDS reads (no W^T copy).
+ * flags: YV_EPI_BIAS, YV_EPI_GELU_BWD (aux = saved pre-activation). */
+int yv_linear_nn(const void* A, int lda, const void* Wkn, int ldw, const float* bias, int M, int N, int K, void* out,
+                 int ldo, int flags, void* aux, int ldaux, void* stream);
+
 /* Weight gradient dW (N,K) f32 = dY^T . X with dY (T,N) and X (T,K) bf16 token-major (T = tokens, a multiple of 64
  * whose tail rows are ZERO): the fragments are columns of the LDS tiles, read with ds_read_b64_tr_b16; no transposed
  * copies.  Split over T when a workspace is registered for the stream (deterministic). */
@@ -252,7 +258,7 @@ int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, f
 /* torch.optim.SGD(momentum, weight_decay) step (utils/trainClass.py:442-443), fp32, in place:
  * g = g*grad_scale + wd*p; m = first ? g : mu*m + g; p -= lr*m.  (grad_scale: 1/world_size after a SUM all-reduce) */
 int yv_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum, float weight_decay,
-                float grad_scale, int first, void* stream);
+                float grad_scale, int first, void* bf16_mirror /* optional: bf16 copy of the updated p */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -209,3 +209,14 @@ def test_wgrad_transposing_gemm(yv, T, N, K):
         dw2 = torch.zeros(N, K, device=DEV)
         yv.wgrad(dyp.to(DEV)[:, :1000], x.to(torch.bfloat16).to(DEV), dw2)
         assert torch.equal(dw2.cpu(), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 768, 2304), (6304, 3072, 768), (64, 128, 64), (33, 768, 1024)])
+def test_linear_nn_reduction_major_weight(yv, M, N, K):
+    """out = A . W with W stored (K,N): exact on small integers (catches operand-map / swizzle errors)."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randint(-3, 4, (M, K), generator=g).float(); w = torch.randint(-2, 3, (K, N), generator=g).float()
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    yv.linear_nn(a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), out)
+    ref = a @ w
+    assert torch.equal(out.cpu().float(), ref.to(torch.bfloat16).float())

@@ -69,6 +69,7 @@ struct GemmArgs {
     int m_mul;
     int tiles_m, tiles_n;
     int group_m;
+    int ldw;                     // WT kernels: row stride of the reduction-major weight (K, N)
     const float* resf;           // f32 residual source (null: read-modify-write `out`)
     uint16_t* aux;               // bf16 side buffer: SAVE_PRE target / GELU_BWD pre-activation
     int ldaux;
@@ -501,10 +502,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
-template <int BM, int BN, int WM, int WN, int ABL = 0>
+// reduction-major tiles ([64 reduction rows][128 columns] bf16, 256-byte LDS rows): chunk swizzle and the
+// hardware-transposing fragment read (8 consecutive reduction elements 32*ks + 8*(lane>>4) + 0..7 of column
+// col0 + (lane&15)): two ds_read_b64_tr_b16, lane 4q+p of a 16-lane group addressing row q, columns 4p..4p+3
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int ks, int lane, int col0) {
+    const int fi = lane & 15, mg = lane >> 4, q = fi >> 2, p = fi & 3;
+    const int row = ks * 32 + mg * 8 + q;
+    const int ch = (col0 + 4 * p) >> 3, off = ((col0 + 4 * p) & 7) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + row * 256 + ((ch ^ tn_swz(row)) << 4) + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + (row + 4) * 256 + ((ch ^ tn_swz(row + 4)) << 4) + off));
+    const u32x4 pk = {__builtin_bit_cast(u32x2, lo)[0], __builtin_bit_cast(u32x2, lo)[1],
+                      __builtin_bit_cast(u32x2, hi)[0], __builtin_bit_cast(u32x2, hi)[1]};
+    return __builtin_bit_cast(bf16x8, pk);
+}
+
+template <int BM, int BN, int WM, int WN, int ABL = 0, bool WT = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
     // ABL (diagnostic builds only): 1 no in-loop DMA, 2 no MFMA, 3 no fragment reads, 4 no epilogue
+    // WT: the weight operand is stored REDUCTION-major, W (K, N) with row stride g.ldw (dgrad: dX = dY . W reads the
+    //     master-layout weight directly): its tile is [64 k][BN n] and its fragments are hardware-transposed reads
     constexpr int NW = WM * WN;                                // waves per workgroup
     constexpr int MF = BM / WM / 16, NF = BN / WN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
@@ -549,10 +569,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int j = 0; j < W_INS; ++j) {
-        const int r = (j * NW + wave) * 8 + lrow;
-        int n = n0 + r;
-        n = n < g.N ? n : g.N - 1;
-        w_src[j] = g.w + (long long)n * g.K + ((lch ^ (r & 7)) << 3);
+        if constexpr (!WT) {
+            const int r = (j * NW + wave) * 8 + lrow;
+            int n = n0 + r;
+            n = n < g.N ? n : g.N - 1;
+            w_src[j] = g.w + (long long)n * g.K + ((lch ^ (r & 7)) << 3);
+        } else {                                           // 4 reduction rows x 256 B per wave-instruction
+            static_assert(!WT || BN == 128, "reduction-major weight tiles are 128 columns wide");
+            const int r = (j * NW + wave) * 4 + (lane >> 4);
+            int cn = n0 + (((lane & 15) ^ tn_swz(r)) << 3);
+            cn = cn < g.N ? cn : g.N - 8;
+            w_src[j] = g.w + (long long)r * g.ldw + cn;
+        }
     }
     auto issue = [&](int kt, int buf) {
         unsigned char* A = smem + buf * (A_BYTES + W_BYTES);
@@ -562,7 +590,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + kt * BK), (lptr_t)(A + (j * NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
         for (int j = 0; j < W_INS; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + kt * BK), (lptr_t)(W + (j * NW + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + (WT ? (long long)kt * BK * g.ldw : (long long)kt * BK)),
+                                             (lptr_t)(W + (j * NW + wave) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[NF][MF];
@@ -597,7 +626,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 const int rr = wrow_n + i * 16 + fr;
-                if (ABL != 3) fw[i] = *(const bf16x8*)(W + rr * 128 + ((kc ^ (rr & 7)) << 4));
+                if (ABL != 3) {
+                    if constexpr (!WT) fw[i] = *(const bf16x8*)(W + rr * 128 + ((kc ^ (rr & 7)) << 4));
+                    else fw[i] = tr_frag(W, ks, lane, wrow_n + i * 16);
+                }
                 else { u32x4 z = {(uint32_t)rr, 5u, 6u, 7u}; fw[i] = __builtin_bit_cast(bf16x8, z); }
             }
 #pragma unroll
@@ -824,10 +856,6 @@ int launch_8phase(GemmArgs& g, hipStream_t st) {
 // Token rows must be padded with ZERO rows up to a multiple of 64 (the trainer allocates its activations so).
 // Few output tiles, long reduction -> always split over the token dimension (deterministic slice-order reduce).
 // ---------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
-
-__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
     // g.a0 = dY (T, N) ld lda0 ; g.w = X (T, K) ld lda1 ; T = g.K (multiple of 64) ; out (N, K) f32 ld ldo
@@ -871,19 +899,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int wk = wave >> 1, wn = wave & 1;                  // 2 x 2 waves, 64 (k) x 64 (n) each
     const int fi = lane & 15, mg = lane >> 4;
-    const int q = fi >> 2, p = fi & 3;                        // address role inside the 16-lane group
 
-    // transposed fragment: 8 consecutive tokens (32*ks + 8*mg + 0..7) of column col0 + fi, from a [64][128] tile
-    auto frag = [&](const unsigned char* tile, int ks, int col0) -> bf16x8 {
-        const int row = ks * 32 + mg * 8 + q;
-        const int ch = ((col0 + 4 * p) >> 3);
-        const int off = ((col0 + 4 * p) & 7) * 2;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + row * 256 + ((ch ^ tn_swz(row)) << 4) + off));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + (row + 4) * 256 + ((ch ^ tn_swz(row + 4)) << 4) + off));
-        const u32x4 pk = {__builtin_bit_cast(u32x2, lo)[0], __builtin_bit_cast(u32x2, lo)[1],
-                          __builtin_bit_cast(u32x2, hi)[0], __builtin_bit_cast(u32x2, hi)[1]};
-        return __builtin_bit_cast(bf16x8, pk);
-    };
+    auto frag = [&](const unsigned char* tile, int ks, int col0) -> bf16x8 { return tr_frag(tile, ks, lane, col0); };
 
     const int nt_all = T / TB;
     const int t0 = (int)((long long)nt_all * slice / S), t1 = (int)((long long)nt_all * (slice + 1) / S);
@@ -928,12 +945,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int ABL = 0, bool WT = false>
 int launch_dma(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     const size_t lds = 2 * (size_t)(BM + BN) * 128;
-    auto kern = gemm_dma_kernel<BM, BN, WM, WN, ABL>;
+    auto kern = gemm_dma_kernel<BM, BN, WM, WN, ABL, WT>;
     if (lds > 65536 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;
@@ -1116,6 +1133,26 @@ static int conv_impl(const yv_view* in0, const yv_view* in1, int B, int Hout, in
         }
     }
     return dispatch<1>(g, (hipStream_t)stream);
+}
+
+extern "C" int yv_linear_nn(const void* A, int lda, const void* Wkn, int ldw, const float* bias, int M, int N, int K,
+                            void* out, int ldo, int flags, void* aux, int ldaux, void* stream) {
+    // out[M,N] = A[M,K] . Wkn[K,N] : the weight is read in its reduction-major layout (dgrad on the master layout)
+    if (!A || !Wkn || !out || M <= 0 || N <= 0 || K <= 0) return YV_ERR_ARG;
+    if ((K % BK) || (lda & 7) || (ldw & 7) || (N & 7) || (ldo & 7)) return YV_ERR_ARG;
+    if (flags & ~(YV_EPI_BIAS | YV_EPI_GELU_BWD)) return YV_ERR_ARG;
+    if ((flags & YV_EPI_BIAS) && !bias) return YV_ERR_ARG;
+    if ((flags & YV_EPI_GELU_BWD) && !aux) return YV_ERR_ARG;
+    if (((uintptr_t)A | (uintptr_t)Wkn | (uintptr_t)out) & 15) return YV_ERR_ARG;
+    GemmArgs g = {};
+    g.a0 = (const uint16_t*)A; g.lda0 = lda; g.c0 = K;
+    g.w = (const uint16_t*)Wkn; g.ldw = ldw; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.out = out; g.ldo = ldo; g.flags = flags; g.aux = (uint16_t*)aux; g.ldaux = ldaux;
+    g.ksize = 1; g.stride = 1; g.splitk = 1;
+    g.staged = epi_can_stage(g);
+    if (!g.staged) return YV_ERR_ARG;
+    g.group_m = g_opt_group_m > 0 ? g_opt_group_m : 8;
+    return launch_dma<128, 128, 2, 2, 0, true>(g, (hipStream_t)stream);
 }
 
 extern "C" int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, int N, int K, float* dW, int ldw,

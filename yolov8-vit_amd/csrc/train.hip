@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ m, size_t n, float lr, float mu, float wd,
-                                                  float gs, int first) {
+                                                  float gs, int first, uint16_t* __restrict__ mirror) {
     const size_t n4 = n >> 2;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
         }
         ((float4*)p)[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
         ((float4*)m)[i] = make_float4(me[0], me[1], me[2], me[3]);
+        if (mirror) ((uint2*)mirror)[i] = make_uint2(pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3]));   // bf16 working copy
     }
     // tail (< 4 elements)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
         float mq = first ? gq : __fadd_rn(__fmul_rn(mu, m[i]), gq);
         m[i] = mq;
         p[i] = __fsub_rn(p[i], __fmul_rn(lr, mq));
+        if (mirror) mirror[i] = f32_to_bf16(p[i]);
     }
 }
 
@@ -89,7 +91,7 @@ extern "C" int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B
 }
 
 extern "C" int yv_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum,
-                           float weight_decay, float grad_scale, int first, void* stream) {
+                           float weight_decay, float grad_scale, int first, void* bf16_mirror, void* stream) {
     if (!p || !g || !m) return YV_ERR_ARG;
     if (n == 0) return YV_OK;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m) & 15) return YV_ERR_ARG;
@@ -97,6 +99,6 @@ extern "C" int yv_sgd_step(float* p, const float* g, float* m, size_t n, float l
     size_t want = (n4 + 255) / 256;
     int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, n, lr, momentum,
-                       weight_decay, grad_scale, first);
+                       weight_decay, grad_scale, first, (uint16_t*)bf16_mirror);
     return yv_launch_status();
 }

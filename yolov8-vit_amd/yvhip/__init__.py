@@ -68,6 +68,7 @@ _SIGS = {
     "yv_linear_ex": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "yv_attention_train": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "yv_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "yv_linear_nn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "yv_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "yv_transpose_bf16": (_i, [_vp, _i, _i, C.c_longlong, _vp, C.c_longlong, _vp]),
     "yv_cast_weights": (_i, [_vp, _i, _i, _vp, _vp, C.c_longlong, _vp]),
@@ -79,7 +80,7 @@ _SIGS = {
     "yv_token_reduce": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "yv_head_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "yv_loss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
-    "yv_sgd_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp]),
+    "yv_sgd_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp, _vp]),
 }
 
 
@@ -280,10 +281,11 @@ def loss_fwd_bwd(logits: torch.Tensor, labels: torch.Tensor, w_lsce: float = 1.0
 
 
 def sgd_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, momentum: float = 0.9,
-             weight_decay: float = 1e-3, first: bool = False, grad_scale: float = 1.0):
-    _chk_dev(p, g, m)
+             weight_decay: float = 1e-3, first: bool = False, grad_scale: float = 1.0,
+             mirror: Optional[torch.Tensor] = None):
+    _chk_dev(p, g, m, mirror)
     check(lib.yv_sgd_step(_p(p), _p(g), _p(m), p.numel(), float(lr), float(momentum), float(weight_decay),
-                          float(grad_scale), 1 if first else 0, _st()), "yv_sgd_step")
+                          float(grad_scale), 1 if first else 0, _p(mirror), _st()), "yv_sgd_step")
 
 
 # ------------------------------------------------------------- dense math
@@ -460,3 +462,14 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, T: Optional[int] 
     check(lib.yv_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), t, dy.shape[1], x.shape[1], _p(dw), dw.stride(0), _st()),
           "yv_wgrad")
     return dw
+
+
+def linear_nn(a: torch.Tensor, w_kn: torch.Tensor, out: torch.Tensor, flags: int = 0, aux: Optional[torch.Tensor] = None,
+              M: Optional[int] = None):
+    """out[M,N] = a[M,K] @ w_kn[K,N] (weight read reduction-major: dgrad on the master layout)."""
+    _chk_dev(a, out, aux)
+    Mr = a.shape[0] if M is None else M
+    K, N = w_kn.shape
+    check(lib.yv_linear_nn(_p(a), a.stride(0), _p(w_kn), w_kn.stride(0), None, Mr, N, K, _p(out), out.stride(0), flags,
+                           _p(aux), 0 if aux is None else aux.stride(0), _st()), "yv_linear_nn")
+    return out

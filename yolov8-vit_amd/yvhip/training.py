@@ -7,9 +7,9 @@ backward] -> SGD(momentum 0.9, weight_decay 1e-3) on fp32 master weights -> bf16
 Memory layout (sized for 288 GB of HBM: nothing is recomputed except softmax probabilities):
   * parameters, gradients and momentum are three FLAT fp32 buffers in state-dict order (64-float aligned
     slots): the optimizer is ONE kernel launch and all-reduce buckets are plain slices;
-  * every GEMM weight has two bf16 working copies, (N,K) for forward/wgrad layout and (K,N) for dgrad;
-  * wgrad runs on the same MFMA GEMM with the token dimension as K, fed by token-major (transposed,
-    zero padded to 64) copies of the activation and of the incoming gradient.
+  * the bf16 working weights are ONE flat mirror of the master buffer, written by the SGD kernel itself;
+  * dgrad (dY . W) and wgrad (dY^T . X) read their reduction-major operands with the gfx950 transposing LDS
+    read, so neither W^T copies nor transposed activations exist; wgrad operands carry 64-row zero padding.
 Gradients arrive in exactly the reverse of the flat order (head first, patch-embed last), so a bucket is
 complete - and its all-reduce can start - as soon as backward has passed its lowest offset.
 """
@@ -20,8 +20,8 @@ from typing import Dict, List, Optional
 import torch
 
 from . import (EPI_GELU, EPI_GELU_BWD, EPI_OUT_F32, EPI_POSEMB, EPI_RES_F32, EPI_SAVE_PRE, YvError, attention_bwd,
-               attention_train, cast_colsum, cast_weights, cls_rows, colsum_bf16, head_bwd, layernorm, layernorm_bwd, lib,
-               linear, linear_ex, loss_fwd_bwd, require_gpu, sgd_step, token_reduce, wgrad, wrapper_head)
+               attention_train, cast_colsum, cls_rows, colsum_bf16, head_bwd, layernorm, layernorm_bwd, lib,
+               linear, linear_ex, linear_nn, loss_fwd_bwd, require_gpu, sgd_step, token_reduce, wgrad, wrapper_head)
 from .engines import vit_cfg
 
 
@@ -55,21 +55,23 @@ class VitTrainer:
         self.P, self.G, self.Mo = z(o), z(o), z(o)
         for k in self.names:
             self.p(k).copy_(state[k].to(self.dev, torch.float32))
-        # ---- bf16 working copies of the GEMM weights ---------------------------------------------
+        # ---- bf16 working copies of the GEMM weights: ONE flat bf16 mirror of P (same offsets), refreshed by the
+        # SGD kernel itself; a GEMM weight is a view into it, used as (N,K) by forward / wgrad and, through the
+        # transposing-read kernel, as the reduction-major operand of dgrad (no W^T copies)
         D = self.D
-        self.gemm_w: Dict[str, tuple] = {}                 # key -> (N, K, wb (Nalloc,K), wt (K, ldN))
-        def reg(key, N, K, n_alloc=None):
-            na = n_alloc or N
-            wb = torch.zeros((na, K), dtype=torch.bfloat16, device=self.dev)
-            wt = torch.zeros((K, _r64(na)), dtype=torch.bfloat16, device=self.dev)
-            self.gemm_w[key] = (N, K, wb, wt)
+        self.P16 = torch.zeros(o, dtype=torch.bfloat16, device=self.dev)
+        self.gemm_w: Dict[str, tuple] = {}                 # key -> (N, K, wb view (N,K))
+        def reg(key, N, K):
+            self.gemm_w[key] = (N, K, self._view16(key).reshape(N, K))
         reg("model.patch_embed.proj.weight", D, 3 * self.P_ * self.P_)
         for i in range(self.L):
             b = f"model.blocks.{i}."
             reg(b + "attn.qkv.weight", 3 * D, D); reg(b + "attn.proj.weight", D, D)
             reg(b + "mlp.fc1.weight", 4 * D, D); reg(b + "mlp.fc2.weight", D, 4 * D)
-        reg("model.head.weight", 1000, D, n_alloc=1024)
+        reg("model.head.weight", 1000, D)
+        self.w_head_pad = torch.zeros((1024, D), dtype=torch.bfloat16, device=self.dev)   # dgrad reduces over 1024
         self.b_head_pad = z(1024)
+        self.P16.copy_(self.P)                               # initial cast (plumbing); afterwards the SGD kernel mirrors
         self.refresh_working_copies()
         self._bufs: Dict[int, dict] = {}
         from .dist import BucketReducer
@@ -82,6 +84,13 @@ class VitTrainer:
         for d in self.shapes[k]:
             n *= d
         return flat[o:o + n].view(self.shapes[k])
+
+    def _view16(self, k):
+        o = self.off[k]
+        n = 1
+        for d in self.shapes[k]:
+            n *= d
+        return self.P16[o:o + n]
 
     def p(self, k):
         return self._view(self.P, k)
@@ -96,8 +105,8 @@ class VitTrainer:
         return {k: self.g(k).detach().clone() for k in self.names}
 
     def refresh_working_copies(self):
-        for k, (N, K, wb, wt) in self.gemm_w.items():
-            cast_weights(self.p(k).reshape(N, K), wb, wt)
+        """Only the 1000 -> 1024 padded head copies need touching: everything else is a view of the mirror."""
+        self.w_head_pad[:1000].copy_(self.gemm_w["model.head.weight"][2])
         self.b_head_pad[:1000].copy_(self.p("model.head.bias"))
 
     # ---- buffers ----------------------------------------------------------------------------------
@@ -156,7 +165,7 @@ class VitTrainer:
             linear_ex(b["g"][i], W(k + "mlp.fc2.weight"), self.p(k + "mlp.fc2.bias"), xout, flags=EPI_RES_F32, res_f32=xmid)
         xf = b["x"][2 * L]
         layernorm(xf, self.p("model.norm.weight"), self.p("model.norm.bias"), b["c"], R, D, N * D, D)
-        linear(b["c"], W("model.head.weight"), self.b_head_pad, b["feats"], flags=EPI_OUT_F32)
+        linear(b["c"], self.w_head_pad, self.b_head_pad, b["feats"], flags=EPI_OUT_F32)
         w1t = self.p("fc.1.weight").t().contiguous()
         b["w1t"] = w1t
         wrapper_head(b["feats"], w1t, self.p("fc.1.bias"), self.p("fc.3.weight"), self.p("fc.3.bias"), R, self.nc,
@@ -177,7 +186,7 @@ class VitTrainer:
         b = self._buffers(R)
         D, N, tok, H, L = self.D, self.N, self.tok, self.H, self.L
         M = R * N
-        Wt = lambda k: self.gemm_w[k][3]
+        Wm = lambda k: self.gemm_w[k][2]                    # master-layout bf16 weight (N_w, K_w)
         self.reducer.reset()
         loss, dlogits = loss_fwd_bwd(b["logits"], labels)
         # ---- Network_Wrapper.fc + backbone head -----------------------------------------------------------
@@ -187,7 +196,7 @@ class VitTrainer:
         colsum_bf16(b["dfeats"], b["ws"][:1024], b["ws"][1024:], rows=R)
         self.g("model.head.bias").copy_(b["ws"][:1000])
         self._wgrad("model.head.weight", b["full"]["dfeats"][:, :1000], b["full"]["c"])
-        linear(b["dfeats"], Wt("model.head.weight"), None, b["dc"])
+        linear_nn(b["dfeats"], self.w_head_pad, b["dc"])
         b["dx"].zero_()
         layernorm_bwd(b["x"][2 * L], N * D, self.p("model.norm.weight"), b["dc"], D, R, D, b["dx"], N * D,
                       self.g("model.norm.weight"), self.g("model.norm.bias"), b["ws"])
@@ -200,20 +209,20 @@ class VitTrainer:
             # MLP branch
             cast_colsum(dx, dxb, self.g(k + "mlp.fc2.bias"), b["ws"])
             self._wgrad(k + "mlp.fc2.weight", b["full"]["dxb"], b["full"]["g"][i])
-            linear_ex(dxb, Wt(k + "mlp.fc2.weight"), None, b["dwide"], flags=EPI_GELU_BWD, aux=b["u"][i])
+            linear_nn(dxb, Wm(k + "mlp.fc2.weight"), b["dwide"], flags=EPI_GELU_BWD, aux=b["u"][i])
             colsum_bf16(b["dwide"], self.g(k + "mlp.fc1.bias"), b["ws"])
             self._wgrad(k + "mlp.fc1.weight", b["full"]["dwide"], b["full"]["h2"][i])
-            linear(b["dwide"], Wt(k + "mlp.fc1.weight"), None, b["dnar"])
+            linear_nn(b["dwide"], Wm(k + "mlp.fc1.weight"), b["dnar"])
             layernorm_bwd(xmid, D, self.p(k + "norm2.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm2.weight"), self.g(k + "norm2.bias"), b["ws"])
             # attention branch
             cast_colsum(dx, dxb, self.g(k + "attn.proj.bias"), b["ws"])
             self._wgrad(k + "attn.proj.weight", b["full"]["dxb"], b["full"]["o"][i])
-            linear(dxb, Wt(k + "attn.proj.weight"), None, b["dnar"])
+            linear_nn(dxb, Wm(k + "attn.proj.weight"), b["dnar"])
             attention_bwd(b["qkv"][i], b["o"][i], b["dnar"], b["lse"][i], R, N, H, b["dqkv"], b["delta"])
             colsum_bf16(b["dqkv"], self.g(k + "attn.qkv.bias"), b["ws"])
             self._wgrad(k + "attn.qkv.weight", b["full"]["dqkv"], b["full"]["h1"][i])
-            linear(b["dqkv"], Wt(k + "attn.qkv.weight"), None, b["dnar"])
+            linear_nn(b["dqkv"], Wm(k + "attn.qkv.weight"), b["dnar"])
             layernorm_bwd(xin, D, self.p(k + "norm1.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm1.weight"), self.g(k + "norm1.bias"), b["ws"])
             self._launch_ready_buckets(self.off[k + "norm1.weight"])
@@ -231,7 +240,8 @@ class VitTrainer:
         import torch.distributed as dist
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.reducer.finish()
-        sgd_step(self.P, self.G, self.Mo, lr, self.momentum, self.wd, first=self.steps == 0, grad_scale=1.0 / world)
+        sgd_step(self.P, self.G, self.Mo, lr, self.momentum, self.wd, first=self.steps == 0, grad_scale=1.0 / world,
+                 mirror=self.P16)
         self.steps += 1
         self.refresh_working_copies()
 
