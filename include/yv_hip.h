@@ -204,7 +204,7 @@ int yv_stem_conv(const uint8_t* images, int B, int H, int W, const float* weight
 /* Forward attention that also returns the per-(crop, head, query) log2-sum-exp for the backward pass. */
 int yv_attention_train(const void* qkv, int R, int N, int H, float scale, void* out, float* lse, void* stream);
 
-/* Attention backward (timm Attention, README.md:21-23; N <= 256): qkv/out/dout as in the forward, lse from
+/* Attention backward (timm Attention, README.md:21-23): qkv/out/dout as in the forward, lse from
  * yv_attention_train; writes dqkv (R*N, 3*H*64) bf16; delta_ws: R*H*N floats of scratch. */
 int yv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int R, int N, int H,
                      float scale, void* dqkv, float* delta_ws, void* stream);

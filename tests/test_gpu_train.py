@@ -81,7 +81,7 @@ def test_layernorm_bwd(yv):
         assert torch.allclose(dga.cpu(), ga.grad, atol=2e-3, rtol=1e-3) and torch.allclose(dbe.cpu(), be.grad, atol=2e-3, rtol=1e-3)
 
 
-@pytest.mark.parametrize("R,N,H", [(2, 197, 3), (1, 50, 2), (2, 33, 1), (1, 256, 2)])
+@pytest.mark.parametrize("R,N,H", [(2, 197, 3), (1, 50, 2), (2, 33, 1), (1, 256, 2), (1, 785, 2), (1, 257, 1), (1, 600, 1)])
 def test_attention_bwd(yv, R, N, H):
     g = torch.Generator().manual_seed(R + N)
     D = H * 64
@@ -131,7 +131,7 @@ def _oracle_grads(sd, x, labels, name):
     return loss.detach(), logits.detach(), {k: v.grad for k, v in p.items()}
 
 
-@pytest.mark.parametrize("name,R", [("vit_tiny_test", 3), ("vit_tiny_test", 33)])
+@pytest.mark.parametrize("name,R", [("vit_tiny_test", 3), ("vit_tiny_test", 33), ("vit_tiny8_test", 2)])
 def test_trainer_gradients_vs_autograd(yv, name, R):
     from oracle import boxes as ob, vit as ov
     from yvhip.training import VitTrainer

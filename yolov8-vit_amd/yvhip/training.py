@@ -38,8 +38,6 @@ class VitTrainer:
         self.name, self.nc, self.img, self.dev = name, num_classes, img, torch.device(device)
         self.tok = (img // self.P_) ** 2
         self.N = self.tok + 1
-        if self.N > 256:
-            raise YvError("the attention backward kernel covers N <= 256 tokens (patch-16 models)")
         self.momentum, self.wd = momentum, weight_decay
         self.steps = 0
         # ---- flat fp32 parameter / gradient / momentum buffers --------------------------------
