@@ -178,6 +178,9 @@ int yv_layernorm(const float* x, size_t ldx, const float* gamma, const float* be
  * (ViT-B/8: 785) are tiled with an online softmax. */
 int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev, void* stream);
 
+/* Diagnostic builds of the attention kernel (0 = normal; 1 no K/V loads, 2 no compute, 3 no V^T writes). */
+int yv_attention_debug(int ablate);
+
 /* cls rows of the token stream: x[r*(tok+1), :] = cls + pos[0]  (timm cls_token + pos_embed) */
 int yv_cls_rows(const float* cls, const float* pos, int R, int tok, int D, float* x, void* stream);
 

@@ -23,8 +23,9 @@
 namespace {
 
 constexpr int HD = 64;
+int g_attn_abl = 0;               // diagnostic builds (yv_attention_debug)
 
-template <int NT>
+template <int NT, int ABL = 0>
 __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __restrict__ qkv, int N, int H, int QB,
                                                             float scale_log2e, uint16_t* __restrict__ out,
                                                             const int32_t* __restrict__ r_dev, float* __restrict__ lse) {
@@ -67,19 +68,22 @@ __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __re
             const int kl = it >> 3, c = it & 7;
             const int key = kv0 + kl;
             uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (key < N) {
+            if (ABL != 1 && key < N) {
                 kv = *(const uint4*)(base + (size_t)key * ld + D + c * 8);
                 vv = *(const uint4*)(base + (size_t)key * ld + 2 * D + c * 8);
             }
             *(uint4*)(Ks + kl * 128 + ((c ^ ((kl >> 1) & 7)) << 4)) = kv;
             const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+            if (ABL != 3) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint16_t val = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
-                *(uint16_t*)(Vt + (c * 8 + e) * VT_STRIDE + kl * 2) = val;
+                for (int e = 0; e < 8; ++e) {
+                    const uint16_t val = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+                    *(uint16_t*)(Vt + (c * 8 + e) * VT_STRIDE + kl * 2) = val;
+                }
             }
         }
         __syncthreads();
+        if (ABL == 2) continue;
 
         // ---- S^T = K . Q^T ------------------------------------------------------------------
         f32x16 s[NT];
@@ -97,26 +101,30 @@ __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __re
         }
 
         // ---- online softmax over this tile's keys (register axis + lane^32) -----------------
+        // only a 32-key group that straddles N needs masking (197 tokens: the last of 7 groups)
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kv0 + kt * 32 + 32 > N) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kv0 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const float v = key < N ? s[kt][e] : -INFINITY;
-                s[kt][e] = v;
-                mx = fmaxf(mx, v);
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kv0 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    s[kt][e] = key < N ? s[kt][e] : -INFINITY;
+                }
             }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);            // every tile holds >= 1 valid key -> finite
-        const float alpha = exp2f((m_run - m_new) * scale_log2e);   // first tile: exp2(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);   // first tile: exp2(-inf) = 0
         const float mb = m_new * scale_log2e;
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = exp2f(s[kt][e] * scale_log2e - mb);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][e], scale_log2e, -mb));    // one v_fma + one v_exp
                 s[kt][e] = p;
                 l += p;
             }
@@ -173,7 +181,7 @@ int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t*
                 hipStream_t st) {
     constexpr int NP = NT * 32;
     const size_t lds = (size_t)NP * 128 + 64 * (size_t)(NP * 2 + 8);
-    auto kern = attention_kernel<NT>;
+    auto kern = g_attn_abl == 1 ? attention_kernel<NT, 1> : g_attn_abl == 2 ? attention_kernel<NT, 2> : g_attn_abl == 3 ? attention_kernel<NT, 3> : attention_kernel<NT, 0>;
     if (lds > 65536 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;
@@ -205,6 +213,8 @@ static int attention_impl(const void* qkv, int R, int N, int H, float scale, voi
         default: return launch_attn<8>(q, R, N, H, scale, o, r_dev, lse, st);
     }
 }
+
+extern "C" int yv_attention_debug(int ablate) { g_attn_abl = ablate; return YV_OK; }
 
 extern "C" int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev,
                             void* stream) {

@@ -61,6 +61,7 @@ _SIGS = {
     "yv_linear": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "yv_layernorm": (_i, [_vp, _sz, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _i, _vp]),
     "yv_attention": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "yv_attention_debug": (_i, [_i]),
     "yv_cls_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "yv_wrapper_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "yv_sppf_pool": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
