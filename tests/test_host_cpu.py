@@ -172,3 +172,28 @@ def test_hot_path_fails_loudly_without_gpu():
     from yvhip import engines
     with pytest.raises(yvhip.YvError):
         engines.YoloEngine(engines.init_yolo_state("n", 5), "n", 5, 64)
+
+
+def test_voc_to_yolo_roundtrip(tmp_path):
+    """generate_annotation -> xml2pd -> YOLO txt: formats either side of the hot path."""
+    import random as _r
+    from PIL import Image
+    from utils.class_config import convert, parse_voc_dir, writeTxt, xml2pd
+    from utils.utils import generate_annotation
+    img_dir = tmp_path / "imgs"; img_dir.mkdir()
+    Image.fromarray(np.zeros((48, 64, 3), np.uint8)).save(img_dir / "m1.png")
+    objs = [{"sort": "broke", "xmin": 4, "ymin": 6, "xmax": 36, "ymax": 30}, {"sort": 4, "xmin": 0, "ymin": 0, "xmax": 64, "ymax": 48}]
+    xml = generate_annotation("imgs", "m1.png", "m1.png", objs, save_dir=str(img_dir) + "/")
+    items = parse_voc_dir(str(img_dir))
+    assert len(items) == 1 and items[0]["width"] == 64 and items[0]["height"] == 48        # size 0/0 in the XML -> image file
+    assert [o["label"] for o in items[0]["objects"]] == [1, 4]
+    _r.seed(0)
+    xml2pd(str(img_dir), yolo_root=str(tmp_path / "yolo"))
+    txts = list((tmp_path / "yolo" / "labels").rglob("m1.txt"))
+    assert len(txts) == 1
+    body = txts[0].read_text()
+    cx, cy, w, h = convert((4, 6, 36, 30), 64, 48)
+    assert body == "1 {:.5f} {:.5f} {:.5f} {:.5f}\\n4 0.50000 0.50000 1.00000 1.00000\\n".format(cx, cy, w, h)   # literal backslash-n
+    assert "\n" not in body and len(list((tmp_path / "yolo" / "images").rglob("m1.png"))) == 1
+    writeTxt(str(tmp_path / "t"), items[0], line_end="\n")
+    assert (tmp_path / "t.txt").read_text().count("\n") == 2
