@@ -172,7 +172,7 @@ def main():
                        "weights": "random-init, seed 42"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "gemm_dma_kernel<128,128|256,256> (all ViT linears)", "launches": n_launch,
+                         "kernel": "gemm_dma_kernel<128,128> (all ViT linears)", "launches": n_launch,
                          "avg_launch_us": ms * 1e3 / max(n_launch, 1),
                          "alg_flop_per_launch": flops / max(n_launch, 1)},
         }

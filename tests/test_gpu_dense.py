@@ -74,6 +74,44 @@ def test_linear_epilogues(yv):
     assert torch.allclose(o2.cpu()[:150], lin[:150], atol=1e-3, rtol=1e-4) and float(o2[150:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("M,N,K,kind", [
+    (25216 // 4, 768, 768, "res"), (6304, 2304, 768, "plain"), (6304, 3072, 768, "gelu"), (6304, 768, 3072, "res"),
+    (1000, 768, 768, "res"), (1000, 1000, 768, "gelu"), (130, 256, 1024, "plain"), (128 * 70 + 5, 640, 768, "gelu"),
+    (70000, 384, 768, "plain")])
+def test_linear_exact_integer(yv, M, N, K, kind):
+    """Small-integer operands make every f32 sum exact, so the forward linears (bias -> bf16, bias + GELU -> bf16,
+    bias + f32 residual read-modify-write) must EQUAL the integer reference element for element: any indexing,
+    swizzle or edge-tile error shows as a wrong integer.  Shapes: many tiles, ragged M / N edges, device-side M."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    bias = torch.randint(-8, 9, (N,), generator=g).float()
+    lin = a @ w.t() + bias                                     # exact: |sum| < 2^24
+    ad, wd, bd = bf(a).to(DEV), bf(w).to(DEV), bias.to(DEV)
+    flags = {"plain": 0, "gelu": yv.EPI_GELU, "res": yv.EPI_RES_F32}[kind]
+    x = torch.randint(-64, 65, (M, N), generator=g).float()
+
+    def run(m_dev=None, m_mul=1):
+        o = x.clone().to(DEV) if kind == "res" else torch.full((M, N), 3.0, dtype=torch.bfloat16, device=DEV)
+        yv.linear(ad, wd, bd, o, flags=flags, m_dev=m_dev, m_mul=m_mul)
+        torch.cuda.synchronize()
+        return o.cpu().float()
+
+    got = run()
+    if kind == "res":
+        assert torch.equal(got, x + lin)
+    elif kind == "plain":
+        assert torch.equal(got, bf(lin).float())
+    else:                                                      # exact argument, erf-GELU within bf16 rounding
+        assert rel_l2(got, F.gelu(lin)) < 3e-3
+    # device-side row count: rows past it keep their old contents
+    md = torch.tensor([M // 3], dtype=torch.int32, device=DEV)
+    part = run(md, 2)
+    cut = 2 * (M // 3)
+    assert torch.equal(part[:cut], got[:cut])
+    assert torch.equal(part[cut:], x[cut:] if kind == "res" else torch.full((M - cut, N), 3.0))
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
