@@ -118,6 +118,17 @@ def check(code: int, what: str = ""):
         raise YvError(f"{what or 'libyvhip'}: {lib.yv_error_string(code).decode()} ({code})")
 
 
+def _apply_env_options():
+    """YV_OPTIONS="key=value,key=value": tuning knobs of yv_set_option for A/B runs (tools/, bench.py)."""
+    spec = os.environ.get("YV_OPTIONS", "")
+    for item in filter(None, (x.strip() for x in spec.split(","))):
+        k, _, v = item.partition("=")
+        set_option(k.strip(), int(v))
+
+
+_apply_env_options()
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise YvError("no HIP device visible: the hot path has no CPU fallback")
