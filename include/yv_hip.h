@@ -263,6 +263,47 @@ int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, f
 int yv_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum, float weight_decay,
                 float grad_scale, int first, void* bf16_mirror /* optional: bf16 copy of the updated p */, void* stream);
 
+/* ---- detector training (the ultralytics trainer behind utils/trainYolo.py:13-35) --------
+ * Conv = conv(no bias) -> BatchNorm2d(eps 1e-3, momentum 0.03) -> SiLU, un-folded; activations are NHWC bf16 views:
+ * (rows = B*H*W, C) with a row stride `ld` (elements), C a multiple of 8, pointers 16-byte aligned. */
+
+/* u8 RGB pixels -> bf16 value/255, channels padded 3 -> 8 with zeros (`blob`, YOLOTensorRT_yolodet_py_解读.md:70-74). */
+int yv_blob_nhwc8(const void* images_u8, long long pixels, void* out_bf16, void* stream);
+
+/* Per-channel batch statistics of z (T,C): mean, rstd = 1/sqrt(biased var + eps); optional running estimates
+ * (run = (1-momentum)*run + momentum*{mean, unbiased var}, both or neither).  ws: yv_bn_ws_floats(T,C) floats. */
+size_t yv_bn_ws_floats(long long T, int C);
+int yv_bn_stats(const void* z, long long ldz, long long T, int C, float eps, float momentum, float* mean, float* rstd,
+                float* run_mean, float* run_var, float* ws, size_t ws_floats, void* stream);
+
+/* a = act(gamma*(z-mean)*rstd + beta) [+ res]   (act 1 = SiLU, 0 = identity); a, res bf16 views. */
+int yv_bn_act_fwd(const void* z, long long ldz, long long T, int C, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, const void* res, long long ldres, void* out, long long ldo,
+                  int act, void* stream);
+
+/* Backward of the above: g = da*act'(u); dbeta = sum g; dgamma = sum g*xhat;
+ * dz = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) with batch statistics, gamma*rstd*g with frozen ones. */
+int yv_bn_act_bwd(const void* da, long long ldda, const void* z, long long ldz, long long T, int C, const float* mean,
+                  const float* rstd, const float* gamma, const float* beta, int act, int batch_stats, float* dgamma,
+                  float* dbeta, void* dz, long long lddz, float* ws, size_t ws_floats, void* stream);
+
+/* Element-wise view operations on (B,H,W,C) bf16 views.  mode 0 copy, 1 dst += src, 2 nearest-2x upsample
+ * (dst (B,2H,2W) <- src (B,H,W)), 3 its adjoint accumulated (dst (B,H,W) += 2x2 block sums of src (B,2H,2W)),
+ * 4 zero insertion (dst (B,2H,2W): [2y][2x] = src[y][x], 0 elsewhere: stride-2 data gradient), 5 zero fill. */
+int yv_view_op(int mode, const void* src, long long ld_src, void* dst, long long ld_dst, int B, int H, int W, int C,
+               void* stream);
+
+/* din += adjoint of max_pool2d(k 5, s 1, p 2) at dout, the maximum of a window being its first one in scan order. */
+int yv_maxpool5_bwd(const void* x, long long ldx, const void* dout, long long lddo, void* din, long long lddi, int B, int H,
+                    int W, int C, void* stream);
+
+/* col (B*Hout*Wout, 9*C) = 3x3 / pad 1 patches of x (B,Hin,Win,C), K order (ky,kx,c): the X operand of yv_wgrad. */
+int yv_im2col3(const void* x, long long ldx, int B, int Hin, int Win, int C, int stride, void* col, void* stream);
+
+/* wd (Cin, taps, Cout) = 180-degree tap flip + in/out transpose of w (Cout, taps, Cin) bf16: the data gradient of a
+ * stride-1 conv is yv_conv2d(dz, wd); of a stride-2 conv the same over the zero-inserted dz (yv_view_op mode 4). */
+int yv_conv_weight_dgrad(const void* w, int Cout, int taps, int Cin, void* wd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

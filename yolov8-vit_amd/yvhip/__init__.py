@@ -54,6 +54,17 @@ _SIGS = {
     "yv_crop_resize_norm": (_i, [_vp, _i, _i, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "yv_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "yv_blob_nhwc8": (_i, [_vp, C.c_longlong, _vp, _vp]),
+    "yv_bn_ws_floats": (_sz, [C.c_longlong, _i]),
+    "yv_bn_stats": (_i, [_vp, C.c_longlong, C.c_longlong, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "yv_bn_act_fwd": (_i, [_vp, C.c_longlong, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, C.c_longlong,
+                           _i, _vp]),
+    "yv_bn_act_bwd": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, C.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp,
+                           _vp, C.c_longlong, _vp, _sz, _vp]),
+    "yv_view_op": (_i, [_i, _vp, C.c_longlong, _vp, C.c_longlong, _i, _i, _i, _i, _vp]),
+    "yv_maxpool5_bwd": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, _vp, C.c_longlong, _i, _i, _i, _i, _vp]),
+    "yv_im2col3": (_i, [_vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp]),
+    "yv_conv_weight_dgrad": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "yv_conv2d": (_i, [C.POINTER(yv_view), C.POINTER(yv_view), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
                        _i, _vp]),
     "yv_conv2d_ws": (_i, [C.POINTER(yv_view), C.POINTER(yv_view), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
@@ -485,3 +496,77 @@ def linear_nn(a: torch.Tensor, w_kn: torch.Tensor, out: torch.Tensor, flags: int
     check(lib.yv_linear_nn(_p(a), a.stride(0), _p(w_kn), w_kn.stride(0), None, Mr, N, K, _p(out), out.stride(0), flags,
                            _p(aux), 0 if aux is None else aux.stride(0), _st()), "yv_linear_nn")
     return out
+
+
+# ------------------------------------------------------------- detector training (row C4)
+VIEW_COPY, VIEW_ADD, VIEW_UP2, VIEW_UP2_BWD, VIEW_ZERO_INSERT, VIEW_ZERO = 0, 1, 2, 3, 4, 5
+
+
+def blob_nhwc8(images: torch.Tensor, out: torch.Tensor):
+    """(B,H,W,3) u8 -> (B,H,W,8) bf16 /255 with zero pad channels."""
+    _chk_dev(images, out)
+    check(lib.yv_blob_nhwc8(_p(images), images.numel() // 3, _p(out), _st()), "yv_blob_nhwc8")
+
+
+def bn_ws_floats(T: int, Cn: int) -> int:
+    return int(lib.yv_bn_ws_floats(T, Cn))
+
+
+def bn_stats(z: "yv_view", T: int, mean, rstd, run_mean, run_var, ws, eps: float = 1e-3, momentum: float = 0.03):
+    check(lib.yv_bn_stats(z.ptr, z.ld, T, z.c, eps, momentum, _p(mean), _p(rstd), _p(run_mean), _p(run_var), _p(ws),
+                          ws.numel(), _st()), "yv_bn_stats")
+
+
+def bn_act_fwd(z: "yv_view", T: int, mean, rstd, gamma, beta, out: "yv_view", res: Optional["yv_view"] = None, act: int = 1):
+    check(lib.yv_bn_act_fwd(z.ptr, z.ld, T, z.c, _p(mean), _p(rstd), _p(gamma), _p(beta), res.ptr if res else None,
+                            res.ld if res else 0, out.ptr, out.ld, act, _st()), "yv_bn_act_fwd")
+
+
+def bn_act_bwd(da: "yv_view", z: "yv_view", T: int, mean, rstd, gamma, beta, dgamma, dbeta, dz: "yv_view", ws,
+               act: int = 1, batch_stats: bool = True):
+    check(lib.yv_bn_act_bwd(da.ptr, da.ld, z.ptr, z.ld, T, z.c, _p(mean), _p(rstd), _p(gamma), _p(beta), act,
+                            1 if batch_stats else 0, _p(dgamma), _p(dbeta), dz.ptr, dz.ld, _p(ws), ws.numel(), _st()),
+          "yv_bn_act_bwd")
+
+
+def view_op(mode: int, src: Optional["yv_view"], dst: "yv_view", B: int, H: int, W: int, Cn: Optional[int] = None):
+    """H, W are the dims of the SMALLER grid for the up / zero-insert modes (see include/yv_hip.h)."""
+    check(lib.yv_view_op(mode, src.ptr if src is not None else None, src.ld if src is not None else 0, dst.ptr, dst.ld, B, H,
+                         W, Cn if Cn is not None else dst.c, _st()), "yv_view_op")
+
+
+def maxpool5_bwd(x: "yv_view", dout: "yv_view", din: "yv_view", B: int, H: int, W: int):
+    check(lib.yv_maxpool5_bwd(x.ptr, x.ld, dout.ptr, dout.ld, din.ptr, din.ld, B, H, W, x.c, _st()), "yv_maxpool5_bwd")
+
+
+def im2col3(x: "yv_view", B: int, Hin: int, Win: int, stride: int, col: torch.Tensor):
+    check(lib.yv_im2col3(x.ptr, x.ld, B, Hin, Win, x.c, stride, _p(col), _st()), "yv_im2col3")
+
+
+def conv_weight_dgrad(w: torch.Tensor, Cout: int, taps: int, Cin: int, wd: torch.Tensor):
+    _chk_dev(w, wd)
+    check(lib.yv_conv_weight_dgrad(_p(w), Cout, taps, Cin, _p(wd), _st()), "yv_conv_weight_dgrad")
+
+
+def conv_view(in0: "yv_view", B: int, Hout: int, Wout: int, ksize: int, stride: int, weight: torch.Tensor, Cout: int,
+              out: "yv_view", flags: int = 0, res: Optional["yv_view"] = None, bias: Optional[torch.Tensor] = None,
+              out_f32: bool = False):
+    """yv_conv2d on views: out (B,Hout,Wout) rows of `out.ld` elements (bf16, or f32 with out_f32); optional bias and
+    bf16 residual view (EPI_RES_BF16 accumulates gradients into a slice)."""
+    if bias is not None:
+        flags |= EPI_BIAS
+    if out_f32:
+        flags |= EPI_OUT_F32
+    if res is not None:
+        flags |= EPI_RES_BF16
+    ws = _conv_workspace(weight.device)
+    check(lib.yv_conv2d_ws(C.byref(in0), None, B, Hout, Wout, ksize, stride, _p(weight), _p(bias), Cout, out.ptr, out.ld,
+                           res.ptr if res is not None else None, res.ld if res is not None else 0, flags, _p(ws),
+                           ws.numel() * 4, _st()), "yv_conv2d_ws")
+
+
+def mview(t: torch.Tensor, c_off: int = 0, c: Optional[int] = None) -> "yv_view":
+    """(rows, ld) or (B,H,W,ld) bf16/f32 tensor -> view of channels [c_off, c_off + c)."""
+    assert t.is_cuda and t.is_contiguous()
+    c = t.shape[-1] - c_off if c is None else c
+    return yv_view(C.c_void_p(t.data_ptr() + t.element_size() * c_off), t.shape[-1], c, 0)
