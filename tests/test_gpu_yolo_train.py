@@ -184,3 +184,138 @@ def test_blob_nhwc8(yv):
     yv.blob_nhwc8(img.to(DEV), out)
     exp = torch.zeros(2, 16, 16, 8); exp[..., :3] = img.float() * torch.tensor(1.0 / 255.0)
     assert torch.equal(out.cpu(), exp.to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------- whole network
+def _oracle_state(scale, nc, seed):
+    from oracle import yolo_train as oy
+    sd = oy.init_train_state(scale, nc, seed)
+    for k in list(sd):
+        if k.endswith("conv.weight") or (k.endswith(".weight") and ".bn." not in k):
+            sd[k] = bf(sd[k]).float()                      # both sides use the same (bf16-representable) conv weights
+    return sd
+
+
+def _act_nchw(a, t):
+    return t[:a.T].float().cpu().view(a.B, a.H, a.W, a.C).permute(0, 3, 1, 2).contiguous()
+
+
+def test_trainer_local_consistency(yv):
+    """Every module of the un-fused YOLOv8n (nc 5, 2 x 160 x 160) checked in isolation: the oracle module
+    (oracle/yolo_train.py, fp32 math with bf16 storage where the device stores bf16) is run on the DEVICE's input
+    activation and back-propagated from the DEVICE's output gradient; outputs, parameter gradients and (summed over
+    all consumers of a tensor) input gradients must agree.  Random-init BatchNorm stacks amplify bf16 storage noise
+    chaotically with depth (fp32 vs bf16 storage: ~10 % at the head, measured with the oracle alone), which is why the
+    comparison is per module.  Tolerances: outputs rel-L2 <= 6e-3; gradients rel-L2 <= 3e-2 (the device also rounds
+    every activation gradient to bf16, the oracle does not)."""
+    from oracle import yolo_train as oy
+    from oracle.yolo import topology
+    from yvhip.yolo_training import YoloTrainer
+    scale, nc, S, B = "n", 5, 160, 2
+    sd = _oracle_state(scale, nc, 3)
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
+    tr = YoloTrainer({k: v.clone() for k, v in sd.items()}, scale=scale, nc=nc, size=S, batch=B)
+    outs = tr.forward(img.to(DEV))
+    R = []
+    for s in range(3):
+        T = outs[s][0].shape[0]
+        db = bf(torch.randn(T, 64, generator=g)).float()
+        dc = torch.zeros(T, 8); dc[:, :nc] = bf(torch.randn(T, nc, generator=g)).float()
+        R.append((db.to(DEV), dc.to(DEV)))
+    tr.backward(R)
+    torch.cuda.synchronize()
+    got = tr.grads()
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    contrib = {}
+    out_err, grad_err = {}, {}
+
+    def add(idx, t):
+        contrib[idx] = contrib.get(idx, 0) + t
+
+    x0 = _act_nchw(tr.x0, tr.x0.buf)[:, :3]
+    topo = {i: (k, a) for i, k, a in topology(scale)}
+    for idx, kind, p in tr.layers:
+        m = tr.mod[idx]
+        if idx == 0:
+            xin = x0.clone().requires_grad_(True)
+        elif "a" in p:                                               # neck: input = concat buffer (checked below)
+            (ia, ua), (ib, _) = p["a"], p["b"]
+            cat = tr.aux[idx]["cat"]
+            xa = _act_nchw(tr.out[ia], tr.out[ia].buf)
+            xb = _act_nchw(tr.out[ib], tr.out[ib].buf)
+            exp = torch.cat([torch.nn.functional.interpolate(xa, scale_factor=2, mode="nearest") if ua else xa, xb], 1)
+            assert torch.equal(_act_nchw(cat, cat.buf), exp), idx
+            xin = exp.clone().requires_grad_(True)
+        else:
+            xin = _act_nchw(tr.out[idx - 1], tr.out[idx - 1].buf).requires_grad_(True)
+        y = oy.run_module(P, idx, xin, scale, train=True, emulate_bf16=True)
+        out_err[idx] = rel_l2(_act_nchw(tr.out[idx], tr.out[idx].buf), y.detach())
+        y.backward(_act_nchw(tr.out[idx], tr.out[idx].grad))
+        if idx == 0:
+            pass
+        elif "a" in p:
+            ca = tr.out[ia].C
+            ga = xin.grad[:, :ca]
+            if ua:
+                ga = ga.view(B, ca, ga.shape[2] // 2, 2, ga.shape[3] // 2, 2).sum((3, 5))
+            add(ia, ga); add(ib, xin.grad[:, ca:])
+        else:
+            add(idx - 1, xin.grad)
+    for s, fidx in enumerate((15, 18, 21)):
+        f = _act_nchw(tr.out[fidx], tr.out[fidx].buf).requires_grad_(True)
+        b, c = oy.run_detect_scale(P, s, f, train=True, emulate_bf16=True)
+        h = b.shape[-1]
+        out_err[f"det{s}.box"] = rel_l2(outs[s][0].cpu().view(B, h, h, 64).permute(0, 3, 1, 2), b.detach())
+        out_err[f"det{s}.cls"] = rel_l2(outs[s][1].cpu().view(B, h, h, 8).permute(0, 3, 1, 2)[:, :nc], c.detach())
+        (b * R[s][0].cpu().view(B, h, h, 64).permute(0, 3, 1, 2)).sum().backward(retain_graph=True)
+        (c * R[s][1].cpu().view(B, h, h, 8).permute(0, 3, 1, 2)[:, :nc]).sum().backward()
+        add(fidx, f.grad)
+    for k, v in P.items():
+        if v.grad is not None:
+            grad_err[k] = rel_l2(got[k], v.grad)
+    in_err = {idx: rel_l2(_act_nchw(tr.out[idx], tr.out[idx].grad), t) for idx, t in contrib.items()}
+    worst_out = max(out_err.items(), key=lambda kv: kv[1])
+    worst_grad = sorted(grad_err.items(), key=lambda kv: -kv[1])[:4]
+    worst_in = max(in_err.items(), key=lambda kv: kv[1])
+    assert worst_out[1] < 6e-3, worst_out
+    assert worst_grad[0][1] < 3e-2, worst_grad
+    assert worst_in[1] < 3e-2, worst_in
+    assert len(grad_err) == 183 and len(in_err) == 16
+
+
+def test_trainer_whole_network_direction(yv):
+    """End to end against pure fp32 autograd with a linear probe loss: chaotic amplification of bf16 storage noise
+    (see test_trainer_local_consistency) allows only a statistical statement - the gradient of every parameter tensor
+    must point the same way (cosine >= 0.75, median >= 0.95)."""
+    from oracle import yolo_train as oy
+    from yvhip.yolo_training import YoloTrainer
+    scale, nc, S, B = "n", 5, 160, 2
+    sd = _oracle_state(scale, nc, 3)
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
+    tr = YoloTrainer({k: v.clone() for k, v in sd.items()}, scale=scale, nc=nc, size=S, batch=B)
+    outs = tr.forward(img.to(DEV))
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    x = bf(img.float() * torch.tensor(1.0 / 255.0)).float().permute(0, 3, 1, 2).contiguous()
+    ref = oy.forward_train(params, x, scale, nc, train=True)
+    R, loss = [], 0.0
+    for s, (rb, rc) in enumerate(ref):
+        h = rb.shape[-1]
+        rbx = bf(torch.randn(rb.shape, generator=g)).float(); rcl = bf(torch.randn(rc.shape, generator=g)).float()
+        loss = loss + (rb * rbx).sum() + (rc * rcl).sum()
+        dc = torch.zeros(B * h * h, 8)
+        dc[:, :nc] = rcl.permute(0, 2, 3, 1).reshape(-1, nc)
+        R.append((rbx.permute(0, 2, 3, 1).reshape(-1, 64).contiguous().to(DEV), dc.to(DEV)))
+    loss.backward()
+    tr.backward(R)
+    torch.cuda.synchronize()
+    got = tr.grads()
+    cos = {k: float(torch.nn.functional.cosine_similarity(got[k].flatten().double(), v.grad.flatten().double(), dim=0))
+           for k, v in params.items() if v.grad is not None and float(v.grad.abs().max()) > 0}
+    vals = sorted(cos.values())
+    assert vals[0] >= 0.75, sorted(cos.items(), key=lambda kv: kv[1])[:5]
+    assert vals[len(vals) // 2] >= 0.95
+    for k in ("model.0", "model.9.cv2", "model.22.cv3.2.1"):
+        assert torch.allclose(tr.run_mean[k].cpu(), params[k + ".bn.running_mean"], atol=5e-3, rtol=5e-2)
+        assert torch.allclose(tr.run_var[k].cpu(), params[k + ".bn.running_var"], atol=5e-3, rtol=5e-2)

@@ -448,6 +448,10 @@ def cast_weights(w: torch.Tensor, w_bf16: torch.Tensor, wt_bf16: torch.Tensor):
     check(lib.yv_cast_weights(_p(w), N, K, _p(w_bf16), _p(wt_bf16), wt_bf16.stride(0), _st()), "yv_cast_weights")
 
 
+def colsum_ws_floats(rows: int, cols: int) -> int:
+    return int(lib.yv_colsum_ws_floats(rows, cols))
+
+
 def cast_colsum(x: torch.Tensor, y_bf16: Optional[torch.Tensor], colsum: Optional[torch.Tensor], ws: torch.Tensor,
                 accumulate: bool = False):
     rows, cols = x.shape
