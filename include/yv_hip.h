@@ -304,6 +304,18 @@ int yv_im2col3(const void* x, long long ldx, int B, int Hin, int Win, int C, int
  * stride-1 conv is yv_conv2d(dz, wd); of a stride-2 conv the same over the zero-inserted dz (yv_view_op mode 4). */
 int yv_conv_weight_dgrad(const void* w, int Cout, int taps, int Cin, void* wd, void* stream);
 
+/* v8 detection loss and its gradient (the objective of `YOLO(pt).train(...)`, utils/trainYolo.py:33; published
+ * ultralytics v8DetectionLoss restated in oracle/yolo_train.py - parity unpinned): DFL decode, TaskAlignedAssigner
+ * (topk 10, alpha 0.5, beta 6; top-k ties by ascending anchor index among the anchors inside the box), CIoU + DFL + BCE,
+ * normalised by the batch sum of target scores, times B.
+ * box[s] (B*h_s*h_s, 64) / cls[s] (B*h_s*h_s, ncp) f32 logits of the three scales (h_s = size / {8,16,32}) and the
+ * matching gradient buffers; gt_boxes (B,G,4) xyxy input pixels, gt_labels (B,G), gt_counts (B) valid boxes per image;
+ * loss (4) = {total*B, box, cls, dfl}.  ws: yv_detect_loss_ws_bytes(B, A, G), A = sum h_s^2. */
+size_t yv_detect_loss_ws_bytes(int B, int A, int G);
+int yv_detect_loss(const float* const* box, const float* const* cls, float* const* dbox, float* const* dcls, int B, int size,
+                   int nc, int ncp, const float* gt_boxes, const int32_t* gt_labels, const int32_t* gt_counts, int G,
+                   float gain_box, float gain_cls, float gain_dfl, float* loss, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

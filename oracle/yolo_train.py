@@ -196,9 +196,11 @@ def assign(pd_scores, pd_boxes, anchors, gt_labels, gt_boxes, mask_gt, topk=10, 
     cls_scores = torch.where(mask, cls_scores, torch.zeros_like(cls_scores))
     align = cls_scores.pow(alpha) * ious.pow(beta)
     # top-k anchors per ground truth by the alignment metric (inside the box only)
-    metric = torch.where(in_gts, align, torch.zeros_like(align))
+    # build-defined tie rule (torch.topk leaves it open): candidates are the anchors inside the box, equal metrics
+    # (e.g. 0 when the predicted box does not overlap) are taken in ascending anchor order
+    metric = torch.where(in_gts, align, torch.full_like(align, -1.0))
     k = min(topk, A)
-    _, idx = metric.topk(k, dim=-1)                                       # ties: lowest index first (stable)
+    idx = metric.sort(dim=-1, descending=True, stable=True).indices[..., :k]
     top = torch.zeros_like(metric, dtype=torch.int32)
     top.scatter_add_(-1, idx, torch.ones_like(idx, dtype=torch.int32))
     mask_pos = (top > 0) & mask

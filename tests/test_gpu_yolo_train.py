@@ -319,3 +319,49 @@ def test_trainer_whole_network_direction(yv):
     for k in ("model.0", "model.9.cv2", "model.22.cv3.2.1"):
         assert torch.allclose(tr.run_mean[k].cpu(), params[k + ".bn.running_mean"], atol=5e-3, rtol=5e-2)
         assert torch.allclose(tr.run_var[k].cpu(), params[k + ".bn.running_var"], atol=5e-3, rtol=5e-2)
+
+
+@pytest.mark.parametrize("B,S,G,counts,seed", [(3, 160, 6, [4, 0, 6], 0), (2, 320, 12, [12, 7], 1), (2, 96, 3, [0, 0], 2),
+                                              (4, 160, 5, [1, 5, 2, 3], 3)])
+def test_detect_loss_vs_oracle(yv, B, S, G, counts, seed):
+    """yv_detect_loss (assigner + CIoU/DFL/BCE + analytic gradient) against oracle/yolo_train.py::detection_loss and
+    torch autograd on the same logits.  f32 on both sides: loss terms rel 2e-4, gradients rel-L2 2e-4.  Cases: images
+    without boxes, a batch without any box (normaliser clamps to 1), many overlapping boxes (anchors claimed by several
+    ground truths), boxes smaller than a stride-32 cell (no anchor inside)."""
+    from oracle import yolo_train as oy
+    nc, ncp = 5, 8
+    g = torch.Generator().manual_seed(seed)
+    hs = [S // 8, S // 16, S // 32]
+    outs, dev_box, dev_cls = [], [], []
+    for h in hs:
+        b = (torch.randn(B, 64, h, h, generator=g) * 1.5).requires_grad_(True)
+        c = (torch.randn(B, nc, h, h, generator=g) * 1.5 - 1.0).requires_grad_(True)
+        outs.append((b, c))
+        dev_box.append(b.detach().permute(0, 2, 3, 1).reshape(-1, 64).contiguous().to(DEV))
+        cp = torch.zeros(B * h * h, ncp); cp[:, :nc] = c.detach().permute(0, 2, 3, 1).reshape(-1, nc)
+        dev_cls.append(cp.to(DEV))
+    ctr = torch.rand(B, G, 2, generator=g) * S
+    wh = torch.rand(B, G, 2, generator=g) * S * 0.45 + 2.0
+    wh[:, 0] = 6.0                                             # a box smaller than the coarse cells
+    gtb = torch.cat([(ctr - wh / 2).clamp(0, S), (ctr + wh / 2).clamp(0, S)], -1)
+    gtl = torch.randint(0, nc, (B, G), generator=g)
+    cnt = torch.tensor(counts, dtype=torch.int32)
+    mask = torch.arange(G)[None] < cnt[:, None]
+    total, (lb, lc, ld) = oy.detection_loss(outs, gtl, gtb, mask, S, nc)
+    total.backward()
+    A = sum(h * h for h in hs)
+    dbox = [torch.full_like(t, 7.0) for t in dev_box]; dcls = [torch.full_like(t, 7.0) for t in dev_cls]
+    loss = torch.zeros(4, device=DEV)
+    ws = torch.zeros(yv.detect_loss_ws_bytes(B, A, G), dtype=torch.uint8, device=DEV)
+    yv.detect_loss(dev_box, dev_cls, dbox, dcls, B, S, nc, ncp, gtb.to(DEV), gtl.to(torch.int32).to(DEV), cnt.to(DEV), loss, ws)
+    torch.cuda.synchronize()
+    got = loss.cpu()
+    for v, r in zip(got, (total.detach(), lb, lc, ld)):
+        assert abs(float(v) - float(r)) <= 2e-4 * max(1.0, abs(float(r))), (got, total, lb, lc, ld)
+    for s, h in enumerate(hs):
+        gb = outs[s][0].grad if outs[s][0].grad is not None else torch.zeros_like(outs[s][0])   # no positives: unused
+        rb = gb.permute(0, 2, 3, 1).reshape(-1, 64)
+        rc = outs[s][1].grad.permute(0, 2, 3, 1).reshape(-1, nc)
+        assert rel_l2(dbox[s].cpu(), rb) < 2e-4 or (float(rb.abs().max()) == 0 and float(dbox[s].abs().max()) == 0), s
+        assert rel_l2(dcls[s].cpu()[:, :nc], rc) < 2e-4, s
+        assert float(dcls[s][:, nc:].abs().max()) == 0

@@ -54,6 +54,8 @@ _SIGS = {
     "yv_crop_resize_norm": (_i, [_vp, _i, _i, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "yv_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "yv_detect_loss_ws_bytes": (_sz, [_i, _i, _i]),
+    "yv_detect_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _sz, _vp]),
     "yv_blob_nhwc8": (_i, [_vp, C.c_longlong, _vp, _vp]),
     "yv_bn_ws_floats": (_sz, [C.c_longlong, _i]),
     "yv_bn_stats": (_i, [_vp, C.c_longlong, C.c_longlong, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -574,3 +576,19 @@ def mview(t: torch.Tensor, c_off: int = 0, c: Optional[int] = None) -> "yv_view"
     assert t.is_cuda and t.is_contiguous()
     c = t.shape[-1] - c_off if c is None else c
     return yv_view(C.c_void_p(t.data_ptr() + t.element_size() * c_off), t.shape[-1], c, 0)
+
+
+def detect_loss_ws_bytes(B: int, A: int, G: int) -> int:
+    return int(lib.yv_detect_loss_ws_bytes(B, A, G))
+
+
+def detect_loss(box, cls, dbox, dcls, B: int, size: int, nc: int, ncp: int, gt_boxes: torch.Tensor, gt_labels: torch.Tensor,
+                gt_counts: torch.Tensor, loss: torch.Tensor, ws: torch.Tensor, gains=(7.5, 0.5, 1.5)):
+    """v8 detection loss + gradient; box/cls/dbox/dcls: lists of the three scales' (rows, 64) / (rows, ncp) f32 tensors."""
+    _chk_dev(*box, *cls, *dbox, *dcls, gt_boxes, gt_labels, gt_counts, loss, ws)
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    G = gt_boxes.shape[1]
+    assert gt_boxes.dtype == torch.float32 and gt_labels.dtype == torch.int32 and gt_counts.dtype == torch.int32
+    check(lib.yv_detect_loss(arr(box), arr(cls), arr(dbox), arr(dcls), B, size, nc, ncp, _p(gt_boxes), _p(gt_labels),
+                             _p(gt_counts), G, gains[0], gains[1], gains[2], _p(loss), _p(ws), ws.numel() * ws.element_size(),
+                             _st()), "yv_detect_loss")
