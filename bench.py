@@ -82,6 +82,49 @@ def bench_train(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def bench_train_yolo(args, rank, world, dev, dist):
+    """BASELINE.json configs[3]: YOLOv8s (nc 80) backbone+head training step at 640x640, 16 images per GPU (128 at
+    DP=8): un-fused forward (BatchNorm batch statistics), v8 detection loss, backward, gradient all-reduce, SGD."""
+    from yvhip.dist import max_over_ranks
+    from yvhip.yolo_training import YoloTrainer, init_yolo_train_state
+    scale, nc, S = "s", 80, 640
+    B = 16 if args.batch == 32 else args.batch
+    tr = YoloTrainer(init_yolo_train_state(scale, nc, seed=42), scale=scale, nc=nc, size=S, batch=B, lr=1e-4, device=str(dev))
+    g = torch.Generator().manual_seed(4321 + rank)
+    images = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).to(dev)
+    G = 8
+    ctr = torch.rand(B, G, 2, generator=g) * S
+    wh = torch.rand(B, G, 2, generator=g) * 240 + 16
+    gtb = torch.cat([(ctr - wh / 2).clamp(0, S), (ctr + wh / 2).clamp(0, S)], -1).to(dev)
+    gtl = torch.randint(0, nc, (B, G), generator=g, dtype=torch.int32).to(dev)
+    gtn = torch.full((B,), G, dtype=torch.int32).to(dev)
+    for _ in range(max(args.warmup, 1)):
+        tr.step(images, gtb, gtl, gtn)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(images, gtb, gtl, gtn)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        flop = 3.0 * 28.60e9 * B                       # fwd + bwd ~ 3 x forward (SURVEY.md section 8(d))
+        print(json.dumps({"metric": "YOLOv8s training images/sec (fwd+loss+bwd+SGD)", "value": world * B * args.steps / dt,
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "YOLOv8s(nc=80) train step, 640x640 (BASELINE.json configs[3])",
+                                     "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                                     "boxes_per_image": G, "loss": [float(v) for v in loss.cpu()]},
+                          "model_tflops_per_gpu": flop * args.steps / dt / 1e12}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,8 +134,9 @@ def main():
     ap.add_argument("--crops", type=int, default=4, help="crops classified per image (cap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no detector/classifier overlap across batches")
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="infer = headline metric (configs[1]); train = ViT-B/16 fine-tune step (configs[2])")
+    ap.add_argument("--mode", choices=["infer", "train", "train-yolo"], default="infer",
+                    help="infer = headline metric (configs[1]); train = ViT-B/16 fine-tune step (configs[2]); "
+                         "train-yolo = YOLOv8s training step (configs[3])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,6 +155,8 @@ def main():
 
     if args.mode == "train":
         return bench_train(args, rank, world, dev, dist)
+    if args.mode == "train-yolo":
+        return bench_train_yolo(args, rank, world, dev, dist)
 
     vit_name = "vit_base_patch16_224"
     yolo_sd = engines.init_yolo_state("n", 5, seed=42, head_gain=4.0)

@@ -365,3 +365,29 @@ def test_detect_loss_vs_oracle(yv, B, S, G, counts, seed):
         assert rel_l2(dbox[s].cpu(), rb) < 2e-4 or (float(rb.abs().max()) == 0 and float(dbox[s].abs().max()) == 0), s
         assert rel_l2(dcls[s].cpu()[:, :nc], rc) < 2e-4, s
         assert float(dcls[s][:, nc:].abs().max()) == 0
+
+
+def test_training_steps_reduce_the_loss(yv):
+    """End to end: 12 SGD steps of YoloTrainer.step on one fixed batch (YOLOv8n, nc 5, 4 x 160 x 160, 3 boxes per
+    image) must bring the v8 loss down, and the state dict must round-trip through the un-fused ultralytics key layout."""
+    from yvhip.yolo_training import YoloTrainer, init_yolo_train_state
+    scale, nc, S, B, G = "n", 5, 160, 4, 3
+    sd = init_yolo_train_state(scale, nc, seed=1)
+    tr = YoloTrainer(sd, scale=scale, nc=nc, size=S, batch=B, lr=2e-3, momentum=0.9, weight_decay=5e-4)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).to(DEV)
+    ctr = torch.rand(B, G, 2, generator=g) * (S - 60) + 30
+    wh = torch.rand(B, G, 2, generator=g) * 50 + 20
+    gtb = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).to(DEV)
+    gtl = torch.randint(0, nc, (B, G), generator=g, dtype=torch.int32).to(DEV)
+    gtn = torch.full((B,), G, dtype=torch.int32, device=DEV)
+    hist = []
+    for _ in range(12):
+        hist.append(tr.step(img, gtb, gtl, gtn).cpu().clone())
+    assert all(torch.isfinite(h).all() for h in hist)
+    first, last = float(hist[0][0]), float(hist[-1][0])
+    assert last < 0.8 * first, [float(h[0]) for h in hist]
+    out = tr.state_dict()
+    assert set(out) == set(sd)
+    tr2 = YoloTrainer(out, scale=scale, nc=nc, size=S, batch=B)
+    assert torch.equal(tr2.P.cpu(), tr.P.cpu())

@@ -17,16 +17,42 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
+import math
+
 from . import (VIEW_ADD, VIEW_COPY, VIEW_UP2, VIEW_UP2_BWD, VIEW_ZERO_INSERT, YvError, blob_nhwc8, bn_act_bwd, bn_act_fwd,
-               bn_stats, bn_ws_floats, cast_colsum, colsum_ws_floats, conv_view, conv_weight_dgrad, im2col3, maxpool5_bwd,
-               mview, require_gpu, sgd_step, sppf_pool, view_op, wgrad)
-from .engines import LAYER_STRIDE, REG_MAX, _c, yolo_layers
+               bn_stats, bn_ws_floats, cast_colsum, colsum_ws_floats, conv_view, conv_weight_dgrad, detect_loss,
+               detect_loss_ws_bytes, im2col3, maxpool5_bwd, mview, require_gpu, sgd_step, sppf_pool, view_op, wgrad)
+from .engines import LAYER_STRIDE, REG_MAX, _c, yolo_conv_keys, yolo_layers
 
 BN_EPS, BN_MOMENTUM = 1e-3, 0.03
 
 
 def _r64(n: int) -> int:
     return (n + 63) // 64 * 64
+
+
+def init_yolo_train_state(scale: str = "n", nc: int = 5, seed: int = 42) -> Dict[str, torch.Tensor]:
+    """Seeded random UN-FUSED weights in the ultralytics key layout (`*.conv.weight`, `*.bn.{weight,bias,running_mean,
+    running_var}`, Detect's `cv2.s.2.{weight,bias}`): there is no network on the box, so benchmarks and smoke tests
+    train from this instead of a downloaded `.pt`."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    for key, ci, co, k in yolo_conv_keys(scale, nc):
+        w = torch.randn(co, ci, k, k, generator=g) * math.sqrt(2.0 / (ci * k * k))
+        if key.endswith(".conv"):
+            base = key[:-5]
+            sd[base + ".conv.weight"] = w
+            sd[base + ".bn.weight"] = torch.ones(co)
+            sd[base + ".bn.bias"] = torch.zeros(co)
+            sd[base + ".bn.running_mean"] = torch.zeros(co)
+            sd[base + ".bn.running_var"] = torch.ones(co)
+        else:
+            sd[key + ".weight"] = w
+            # ultralytics Detect.bias_init: box branch 1.0, class branch log(5 / nc / (640 / stride)^2)
+            s_idx = int(key.split(".")[3])
+            sd[key + ".bias"] = (torch.full((co,), 1.0) if ".cv2." in key else
+                                 torch.full((co,), math.log(5 / nc / (640 / (8 << s_idx)) ** 2)))
+    return sd
 
 
 class _Act:
@@ -80,6 +106,10 @@ class YoloTrainer:
         self._alloc_params(state)
         self._alloc_buffers()
         self.step_count = 0
+        self.loss_out = torch.zeros(4, device=self.dev)
+        self._loss_ws: Dict[int, torch.Tensor] = {}
+        from .dist import BucketReducer
+        self.reducer = BucketReducer(self.G, 1 << 62)            # 12-45 MB of gradients: one all-reduce after backward
 
     # ------------------------------------------------------------------ parameters
     def _param(self, name: str, n: int, group: str) -> int:
@@ -434,6 +464,35 @@ class YoloTrainer:
                 for q in (2, 1, 0):                       # p_{q+1} = maxpool(p_q)
                     maxpool5_bwd(y.v(q * c_, c_), y.g((q + 1) * c_, c_), y.g(q * c_, c_), B, y.H, y.W)
                 self._bwd(m["cv1"], y.g(0, c_), o[idx - 1].buf, 0, o[idx - 1].g())
+
+    # ------------------------------------------------------------------ loss / step
+    def loss(self, gt_boxes: torch.Tensor, gt_labels: torch.Tensor, gt_counts: torch.Tensor, gains=(7.5, 0.5, 1.5)):
+        """v8 detection loss of the last forward; fills the d-logit buffers backward() consumes.
+        gt_boxes (B,G,4) f32 xyxy input pixels, gt_labels (B,G) i32, gt_counts (B) i32, all on the device.
+        Returns the device tensor {total*B, box, cls, dfl} (no host sync)."""
+        B, G = self.B, gt_boxes.shape[1]
+        if tuple(gt_boxes.shape) != (B, G, 4) or tuple(gt_labels.shape) != (B, G) or tuple(gt_counts.shape) != (B,):
+            raise YvError("targets must be gt_boxes (B,G,4), gt_labels (B,G), gt_counts (B)")
+        A = sum((self.size // st) ** 2 for st in (8, 16, 32))
+        if G not in self._loss_ws:
+            self._loss_ws[G] = torch.zeros(detect_loss_ws_bytes(B, A, G), dtype=torch.uint8, device=self.dev)
+        do = self.det_out
+        detect_loss([d["box"] for d in do], [d["cls"] for d in do], [d["dbox"] for d in do], [d["dcls"] for d in do], B,
+                    self.size, self.nc, self.ncp, gt_boxes, gt_labels, gt_counts, self.loss_out, self._loss_ws[G], gains)
+        return self.loss_out
+
+    def step(self, images: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torch.Tensor, gt_counts: torch.Tensor,
+             lr: Optional[float] = None):
+        """forward -> loss -> backward -> (data-parallel SUM all-reduce, mean folded into the update) -> SGD."""
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.forward(images)
+        loss = self.loss(gt_boxes, gt_labels, gt_counts)
+        self.reducer.reset()
+        self.backward()
+        self.reducer.finish()
+        self.optimizer_step(lr, grad_scale=1.0 / world)
+        return loss
 
     # ------------------------------------------------------------------ optimiser
     def optimizer_step(self, lr: Optional[float] = None, grad_scale: float = 1.0):
