@@ -163,3 +163,42 @@ def test_train_one_epoch_surface(tmp_path):
     acc1, loss1 = tc.valid_one_epoch(net, tc.build_loss, loader[:3])
     assert loss1 < loss0                                            # three epochs on 6 samples reduce the loss
     assert abs(opt.param_groups[0]["lr"] - tc.cosine_anneal_schedule(2, 10, 0.01)) < 1e-12
+
+
+def test_train_yolo_surface(tmp_path):
+    """utils.trainYolo.train(epochs, batch, data) (utils/trainYolo.py:6-35) on a dataset produced by the reference's own
+    file formats: generate_annotation XML -> xml2pd -> images/labels tree -> data yaml -> 3 epochs of the device
+    training step.  The loss must fall and the written weights must load back."""
+    import random as _r
+    from PIL import Image
+    import numpy as np
+    import utils.trainYolo as ty
+    from utils.class_config import xml2pd
+    from utils.utils import generate_annotation
+    rng = np.random.default_rng(0)
+    src = tmp_path / "new"; src.mkdir()
+    for i in range(6):
+        img = rng.integers(90, 130, (96, 128, 3), dtype=np.uint8)
+        x0, y0 = int(rng.integers(8, 60)), int(rng.integers(8, 40))
+        img[y0:y0 + 40, x0:x0 + 48] = (220, 40, 40) if i % 2 else (40, 40, 220)
+        Image.fromarray(img).save(src / f"im{i}.png")
+        generate_annotation("new", f"im{i}.png", f"im{i}.png",
+                            [{"sort": i % 2, "xmin": x0, "ymin": y0, "xmax": x0 + 48, "ymax": y0 + 40}], save_dir=str(src) + "/")
+    _r.seed(3)
+    root = tmp_path / "yolo" / "fold0"
+    xml2pd(str(src), yolo_root=str(root))
+    n_train = len(list((root / "images" / "train").glob("*.png")))
+    assert n_train >= 3
+    (tmp_path / "config.yaml").write_text(f"path: {root}\ntrain: images/train\nval: images/val\nnc: 5\n"
+                                          "names: ['good', 'broke', 'lose', 'uncovered', 'circle']\n")
+    logs = []
+    res = ty.train(epochs=3, batch=2, data=str(tmp_path / "config.yaml"), size=128, save=str(tmp_path / "w" / "best.pth"),
+                   log=logs.append)
+    assert len(res["epochs"]) == 3 and res["epochs"][0]["steps"] == n_train // 2 and "EMA" in res["not_built"]
+    assert all(np.isfinite(e["loss"]) for e in res["epochs"])
+    assert res["epochs"][0]["lr"] == pytest.approx(1e-4) and res["epochs"][2]["lr"] < res["epochs"][1]["lr"]
+    sd = torch.load(res["weights"], map_location="cpu", weights_only=True)
+    assert "model.0.conv.weight" in sd and "model.22.cv3.2.2.bias" in sd and sd["model.0.bn.running_var"].shape == (16,)
+    res2 = ty.train(epochs=1, batch=2, data=str(tmp_path / "config.yaml"), size=128, weights=res["weights"],
+                    save=str(tmp_path / "w" / "again.pth"), log=logs.append)
+    assert res2["epochs"][0]["steps"] == n_train // 2 and not any("random initialisation" in l for l in logs[-2:])

@@ -110,7 +110,9 @@ def test_star_import_surface():
                  "set_seed", "CFG"):
         assert hasattr(tc, name), name
     import utils.trainYolo as ty
-    assert list(inspect.signature(ty.train).parameters) == ["epochs", "batch", "data"] and callable(ty.yoloRetrain)
+    sig = inspect.signature(ty.train).parameters
+    assert list(sig)[:3] == ["epochs", "batch", "data"] and callable(ty.yoloRetrain)
+    assert all(p.default is not inspect.Parameter.empty for p in list(sig.values())[3:])    # reference call still binds
 
 
 def test_eval_transform_matches_oracle_rule():
@@ -197,3 +199,36 @@ def test_voc_to_yolo_roundtrip(tmp_path):
     assert "\n" not in body and len(list((tmp_path / "yolo" / "images").rglob("m1.png"))) == 1
     writeTxt(str(tmp_path / "t"), items[0], line_end="\n")
     assert (tmp_path / "t.txt").read_text().count("\n") == 2
+
+
+def test_yolo_dataset_reader(tmp_path):
+    """YOLO-format tree as utils/class_config.py:89-148 writes it -> letterboxed batch + pixel boxes
+    (yvhip/yolo_data.py, the host side of utils.trainYolo.train); label records separated by the reference writer's
+    literal backslash-n or by real newlines."""
+    from PIL import Image
+    from yvhip.yolo_data import letterbox_host, list_samples, load_batch, max_boxes_per_image, parse_label_text, read_data_yaml
+    root = tmp_path / "fold0"
+    for split in ("train", "val"):
+        (root / "images" / split).mkdir(parents=True)
+        (root / "labels" / split).mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    Image.fromarray(rng.integers(0, 256, (40, 80, 3), dtype=np.uint8)).save(root / "images" / "train" / "b.png")
+    Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(root / "images" / "train" / "a.png")
+    (root / "labels" / "train" / "b.txt").write_text("1 0.5 0.5 0.25 0.5\\n3 0.25 0.25 0.1 0.1\\n")       # literal backslash-n
+    (root / "labels" / "train" / "a.txt").write_text("0 0.5 0.5 1.0 1.0\n")
+    (tmp_path / "config.yaml").write_text(f"path: {root}\ntrain: images/train\nval: images/val\nnc: 5\n"
+                                          "names: ['good', 'broke', 'lose', 'uncovered', 'circle']\n")
+    cfg = read_data_yaml(str(tmp_path / "config.yaml"))
+    assert cfg["nc"] == 5 and cfg["train"] == str(root / "images" / "train")
+    samples = list_samples(cfg["train"])
+    assert [os.path.basename(a) for a, _ in samples] == ["a.png", "b.png"]
+    assert samples[1][1] == str(root / "labels" / "train" / "b.txt")
+    assert parse_label_text("1 0.5 0.5 0.25 0.5\\n3 0.25 0.25 0.1 0.1\\n").shape == (2, 5)
+    assert max_boxes_per_image(samples) == 2
+    img, gtb, gtl, gtn = load_batch(samples, 64, 2)
+    assert tuple(img.shape) == (2, 64, 64, 3) and img.dtype == torch.uint8 and gtn.tolist() == [1, 2]
+    assert gtb[0, 0].tolist() == [0.0, 0.0, 64.0, 64.0] and gtl[0, 0] == 0
+    # 80x40 image into 64x64: r = 0.8, content 64x32, top pad 16; box (30..50, 10..30) -> (24..40, 24..40)
+    assert np.allclose(gtb[1, 0].numpy(), [24.0, 24.0, 40.0, 40.0]) and gtl[1].tolist() == [1, 3]
+    lb, r, (left, top) = letterbox_host(np.zeros((40, 80, 3), np.uint8), 64)
+    assert (r, left, top) == (0.8, 0, 16) and lb[0, 0, 0] == 114 and lb[16, 0, 0] == 0 and lb[47, 0, 0] == 0 and lb[48, 0, 0] == 114
