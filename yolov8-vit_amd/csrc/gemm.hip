@@ -1168,10 +1168,16 @@ extern "C" int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, 
     g.splitk = 1;
     if (ws_lookup(stream, &ws, &wsb)) {
         const long long tiles = (long long)g.tiles_m * g.tiles_n;
+        // ViT weight gradients: 100+ tiles over 6k tokens -> S <= 9.  Conv weight gradients: 1-4 tiles over 10^5..10^6
+        // output pixels -> up to 512 slices of >= 512 rows each (the partials stay tiny: S * Cout * 9*Cin floats)
         int S = (int)(1024 / tiles);
-        if (S > T / 64 / 2) S = T / 64 / 2;
-        if (S > 16) S = 16;
-        if (S >= 2 && (size_t)S * N * K * sizeof(float) <= wsb) { g.splitk = S; g.partial = (float*)ws; }
+        const int cap = tiles <= 16 ? 512 : 16;
+        const int min_rows = tiles <= 16 ? 512 : 128;
+        if (S > T / min_rows) S = T / min_rows;
+        if (S > cap) S = cap;
+        const size_t fit = wsb / ((size_t)N * K * sizeof(float));
+        if ((size_t)S > fit) S = (int)fit;
+        if (S >= 2) { g.splitk = S; g.partial = (float*)ws; }
     }
     const int S = g.splitk;
     const size_t lds = 2 * 2 * 64 * 256;

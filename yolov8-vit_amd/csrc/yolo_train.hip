@@ -107,14 +107,31 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(RedArgs a) {
     }
 }
 
+// Second stage: one workgroup per 8 channels; 32 chunk lanes sum every 32nd chunk (double), lane order fixes the
+// final summation order (bitwise reproducible).
+__device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, int chunks, int C, int c, double& s, double& ss,
+                                           double* sh) {
+    const int lane = threadIdx.x >> 3;                       // 0..31
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int k = lane; k < chunks; k += 32) { a += partial[((long long)k * 2) * C + c]; b += partial[((long long)k * 2 + 1) * C + c]; }
+    sh[(lane * 8 + (threadIdx.x & 7)) * 2] = a;
+    sh[(lane * 8 + (threadIdx.x & 7)) * 2 + 1] = b;
+    __syncthreads();
+    s = 0.0; ss = 0.0;
+    if (lane == 0)
+        for (int l = 0; l < 32; ++l) { s += sh[(l * 8 + threadIdx.x) * 2]; ss += sh[(l * 8 + threadIdx.x) * 2 + 1]; }
+}
+
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ partial, int chunks, int C, long long T,
                                                              float eps, float* __restrict__ mean, float* __restrict__ rstd,
                                                              float* __restrict__ run_mean, float* __restrict__ run_var,
                                                              float momentum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < chunks; ++k) { s += partial[((long long)k * 2) * C + c]; ss += partial[((long long)k * 2 + 1) * C + c]; }
+    __shared__ double sh[512];
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    double s, ss;
+    chunk_sums(partial, chunks, C, c, s, ss, sh);
+    if (threadIdx.x >= 8 || c >= C) return;
     const double m = s / (double)T;
     double var = ss / (double)T - m * m;
     var = var > 0.0 ? var : 0.0;
@@ -130,10 +147,11 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int chunks, int C, long long T,
                                                            int batch_stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ coef /* (2, C): mean(g), mean(g*xhat) */) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int k = 0; k < chunks; ++k) { s += partial[((long long)k * 2) * C + c]; sx += partial[((long long)k * 2 + 1) * C + c]; }
+    __shared__ double sh[512];
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    double s, sx;
+    chunk_sums(partial, chunks, C, c, s, sx, sh);
+    if (threadIdx.x >= 8 || c >= C) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)sx;
     coef[c] = batch_stats ? (float)(s / (double)T) : 0.f;
@@ -350,7 +368,7 @@ extern "C" int yv_bn_stats(const void* z, long long ldz, long long T, int C, flo
     const int chunks = chunks_for(T, &a.rows_per_chunk);
     const int rp = 256 / (C >> 3);
     hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(chunks), dim3(256), (size_t)rp * 2 * C * sizeof(float), (hipStream_t)stream, a);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, chunks, C, T, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, ws, chunks, C, T, eps,
                        mean, rstd, run_mean, run_var, momentum);
     return yv_launch_status();
 }
@@ -383,7 +401,7 @@ extern "C" int yv_bn_act_bwd(const void* da, long long ldda, const void* z, long
     const int rp = 256 / (C >> 3);
     float* coef = ws + (size_t)chunks * 2 * C;
     hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(chunks), dim3(256), (size_t)rp * 2 * C * sizeof(float), (hipStream_t)stream, r);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, chunks, C, T,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, ws, chunks, C, T,
                        batch_stats, dgamma, dbeta, coef);
     ActArgs a = {};
     a.z = (const uint16_t*)z; a.ldz = ldz; a.da = (const uint16_t*)da; a.ldda = ldda; a.out = (uint16_t*)dz; a.ldo = lddz;
