@@ -1171,7 +1171,7 @@ extern "C" int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, 
         // ViT weight gradients: 100+ tiles over 6k tokens -> S <= 9.  Conv weight gradients: 1-4 tiles over 10^5..10^6
         // output pixels -> up to 512 slices of >= 512 rows each (the partials stay tiny: S * Cout * 9*Cin floats)
         int S = (int)(1024 / tiles);
-        const int cap = tiles <= 16 ? 512 : 16;
+        const int cap = tiles <= 16 ? 256 : 16;
         const int min_rows = tiles <= 16 ? 512 : 128;
         if (S > T / min_rows) S = T / min_rows;
         if (S > cap) S = cap;
