@@ -26,6 +26,7 @@
 namespace {
 
 constexpr int BK = 64;            // bf16 elements per K step
+int g_opt_wgrad_cap = 128;          // token slices of a conv-shaped weight gradient (few output tiles, 10^5+ rows)
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
 int g_opt_group_m = 8;
 int g_opt_staged = 1;
@@ -1013,6 +1014,7 @@ extern "C" int yv_set_workspace(void* stream, void* ws, size_t bytes) {
 extern "C" int yv_set_option(const char* key, int value) {
     if (!key) return YV_ERR_ARG;
     if (!strcmp(key, "linear_variant")) { g_opt_variant = value; return YV_OK; }
+    if (!strcmp(key, "wgrad_split_cap")) { g_opt_wgrad_cap = value; return YV_OK; }
     if (!strcmp(key, "linear_group_m")) { g_opt_group_m = value; return YV_OK; }
     if (!strcmp(key, "staged_epilogue")) { g_opt_staged = value; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
@@ -1171,7 +1173,7 @@ extern "C" int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, 
         // ViT weight gradients: 100+ tiles over 6k tokens -> S <= 9.  Conv weight gradients: 1-4 tiles over 10^5..10^6
         // output pixels -> up to 512 slices of >= 512 rows each (the partials stay tiny: S * Cout * 9*Cin floats)
         int S = (int)(1024 / tiles);
-        const int cap = tiles <= 16 ? 256 : 16;
+        const int cap = tiles <= 16 ? g_opt_wgrad_cap : 16;
         const int min_rows = tiles <= 16 ? 512 : 128;
         if (S > T / min_rows) S = T / min_rows;
         if (S > cap) S = cap;
