@@ -202,3 +202,49 @@ def test_train_yolo_surface(tmp_path):
     res2 = ty.train(epochs=1, batch=2, data=str(tmp_path / "config.yaml"), size=128, weights=res["weights"],
                     save=str(tmp_path / "w" / "again.pth"), log=logs.append)
     assert res2["epochs"][0]["steps"] == n_train // 2 and not any("random initialisation" in l for l in logs[-2:])
+
+
+def test_train_class_from_xml_directories(tmp_path):
+    """utils.trainClass.train(CFG, log) (utils/trainClass.py:424-508) end to end on directories of VOC xml + images as
+    app.py's annotation flow leaves them: deliver() 80/20 split -> xml2pd -> build_dataset / DataLoader -> epochs of
+    the native fine-tune step -> best.pth + result.json."""
+    import json as _json
+    import random as _r
+    import numpy as np
+    from PIL import Image
+    import utils.trainClass as tc
+    from utils.utils import generate_annotation
+    rng = np.random.default_rng(0)
+    new = tmp_path / "new"; new.mkdir()
+    for i in range(10):
+        img = rng.integers(60, 200, (80, 100, 3), dtype=np.uint8)
+        Image.fromarray(img).save(new / f"w{i}.png")
+        objs = [{"sort": ["good", "broke", "lose", "uncovered", "circle"][i % 5], "xmin": 10, "ymin": 8, "xmax": 70, "ymax": 60}]
+        if i % 3 == 0:
+            objs.append({"sort": "circle", "xmin": 30, "ymin": 20, "xmax": 90, "ymax": 70})
+        generate_annotation("new", f"w{i}.png", f"w{i}.png", objs, save_dir=str(new) + "/")
+    (new / "orphan.png").write_bytes((new / "w0.png").read_bytes())                     # image without xml: skipped
+    _r.seed(1)
+    tc.deliver(str(new) + "/", str(tmp_path / "tr"), str(tmp_path / "va"))
+    n_tr = len(list((tmp_path / "tr").glob("*.xml"))); n_va = len(list((tmp_path / "va").glob("*.xml")))
+    assert n_tr + n_va == 10 and n_tr >= 5 and n_va >= 1 and (new / "orphan.png").exists()
+
+    class C(_CFG):
+        modelName = "vit_tiny_test"
+        pretrained = str(tmp_path / "missing.pth")
+        train_path = [str(tmp_path / "tr"), str(tmp_path / "does_not_exist")]
+        valid_path = [str(tmp_path / "va")]
+        epoch, lr, train_bs, valid_bs = 2, 5e-3, 2, 4
+        img_size = [224, 224]
+    objs, circ = tc.xml2pd(C.train_path)
+    assert len(objs) + len(circ) == sum(1 + (int(p.stem[1:]) % 3 == 0) for p in (tmp_path / "tr").glob("*.png"))
+    assert all(o["objects"]["label"] == 4 for o in circ) and all(o["objects"]["label"] != 4 for o in objs)
+    ds = tc.build_dataset(objs, circ, val=True, transforms=tc.build_transforms(C)["valid_test"])
+    x, y, path = ds[0]
+    assert tuple(x.shape) == (3, 224, 224) and x.dtype == torch.float32 and int(y.sum()) == 1 and os.path.exists(path)
+    res = tc.train(C, log=str(tmp_path / "result.json"), save_path=str(tmp_path / "out" / "best.pth"))
+    assert sorted(res) == [1, 2] and all(0.0 <= r["val_acc"] <= 100.0 and np.isfinite(r["loss"]) for r in res.values())
+    assert sorted(_json.load(open(tmp_path / "result.json"))) == ["1", "2"]
+    if any(r["val_acc"] > 0 for r in res.values()):
+        sd = torch.load(tmp_path / "out" / "best.pth", map_location="cpu", weights_only=True)
+        assert "model.cls_token" in sd and "fc.3.weight" in sd

@@ -3,8 +3,9 @@
 Hot-path pieces run on the HIP kernels: `build_model`/`Network_Wrapper` (ViT engine), `build_loss` +
 `LabelSmoothingCrossEntropy` + `FocalLoss` (fused loss kernel with its analytic gradient),
 `getCorrect` (device argmax), the eval transform and `crop_image`'s integer inflate.  `train_one_epoch` / `valid_one_epoch`
-run the native fine-tune step (yvhip.training).  Dataset walking, XML parsing, ONNX export and the augmentation
-zoo are outside SURVEY.md section 8 and are not rebuilt.
+run the native fine-tune step (yvhip.training).  The dataset front-end (`xml2pd`, `build_dataset`, `build_dataloader`,
+`deliver`, `train`, `retrain`) follows the reference on the host; ONNX export and the stochastic augmentation zoo
+ are not rebuilt.
 """
 import json
 import math
@@ -248,11 +249,144 @@ def train_one_epoch(net, netp, trainloader, CELoss, optimizer, lr, batch_size, e
     return correct
 
 
-def train(CFG, log=False):
-    """utils/trainClass.py:424-508 walks VOC XML directories on disk (xml2pd / build_dataset): that dataset
-    front-end is outside SURVEY.md section 8 and is not rebuilt; drive `train_one_epoch` / `valid_one_epoch`
-    with any loader yielding (inputs (B,3,224,224), one-hot targets (B,nc), path)."""
-    raise yvhip.YvError("dataset walking (xml2pd/build_dataset) is out of scope: call train_one_epoch with a loader")
+# ------------------------------------------------------------------------------- dataset front-end
+LABEL_MAPPING = {'good': 0, 'broke': 1, 'lose': 2, 'loss': 2, 'uncovered': 3, 'circle': 4}      # utils/trainClass.py:278-285
+SKIP_IMAGES = ('well5_0011.jpg',)                                                                 # :298
+
+
+def xml2pd(directory):
+    """utils/trainClass.py:277-327: VOC xml files directly inside each listed directory -> (objects, objects_circle),
+    one entry per annotated object, both lists shuffled (random.shuffle, objects first).  Class names come from
+    <name> (falling back to <sort>); numeric ids written by generate_annotation (<sort>3</sort>) are accepted too."""
+    import xml.etree.ElementTree as ET
+    objects, objects_circle = [], []
+    for d in directory:
+        if not os.path.isdir(d):
+            continue
+        for file in sorted(os.listdir(d)):
+            if not file.endswith(".xml"):
+                continue
+            path = os.path.join(d, file)
+            root = ET.parse(path).getroot()
+            data_path = os.path.normpath(os.path.join(os.path.dirname(path), root.find('path').text))
+            if os.path.basename(data_path) in SKIP_IMAGES:
+                continue
+            name = os.path.splitext(root.find('filename').text)[0]
+            for obj in root.findall('.//object'):
+                tag = obj.find('name') if obj.find('name') is not None else obj.find('sort')
+                sort = tag.text
+                label = LABEL_MAPPING[sort] if sort in LABEL_MAPPING else int(sort)
+                temp = {'name': sort, 'label': label, 'xmin': int(obj.find('.//xmin').text), 'ymin': int(obj.find('.//ymin').text),
+                        'xmax': int(obj.find('.//xmax').text), 'ymax': int(obj.find('.//ymax').text)}
+                (objects_circle if label == 4 else objects).append(
+                    {'path': data_path, 'objects': temp, "width": 0, "height": 0, "name": name})
+    random.shuffle(objects)
+    random.shuffle(objects_circle)
+    return objects, objects_circle
+
+
+class build_dataset(torch.utils.data.Dataset):
+    """utils/trainClass.py:227-273: training draws from `objects` or `objects_circle` with the circle share as the
+    switch probability (one random.random() per item), validation is the concatenation; crops use crop_image
+    (random inflation when training) and the given transform; items are (CHW float tensor, one-hot int64, path)."""
+
+    def __init__(self, objects, objects_circle, val=False, train_val_flag=True, transforms=None):
+        self.objects, self.objects_circle = objects, objects_circle
+        self.train_val_flag, self.transforms, self.val = train_val_flag, transforms, val
+        self.lenth_cir, self.lenth = len(objects_circle), len(objects)
+        self.rate = self.lenth_cir / (self.lenth + self.lenth_cir) if (self.lenth + self.lenth_cir) > 0 else 0
+        if val:
+            self.dataset = objects + objects_circle
+
+    def __len__(self):
+        return len(self.objects_circle) + len(self.objects)
+
+    def __getitem__(self, index):
+        if not self.val:
+            if random.random() > self.rate:
+                obj = self.objects[index % self.lenth if self.lenth > 0 else 0]
+            else:
+                obj = self.objects_circle[index % self.lenth_cir if self.lenth_cir > 0 else 0]
+        else:
+            obj = self.dataset[index]
+        o = obj['objects']
+        img = crop_image(obj["path"], o["xmin"], o["ymin"], o["xmax"], o["ymax"], training=not self.val)
+        data = self.transforms(image=np.array(img))
+        chw = torch.from_numpy(np.ascontiguousarray(np.transpose(data['image'], (2, 0, 1))))
+        if not self.train_val_flag:
+            return chw, obj["path"]
+        label = torch.nn.functional.one_hot(torch.tensor(o["label"]), num_classes=CFG.num_classes)
+        return chw, label.to(torch.int64), obj["path"]
+
+
+def build_dataloader(objects, objects_circle, valid_objects, valid_objects_circle, data_transforms):
+    """utils/trainClass.py:331-341 (train: shuffle, drop_last=False; valid: in order)."""
+    from torch.utils.data import DataLoader
+    train_dataset = build_dataset(objects, objects_circle, val=False, train_val_flag=True, transforms=data_transforms['train'])
+    valid_dataset = build_dataset(valid_objects, valid_objects_circle, val=True, train_val_flag=True,
+                                  transforms=data_transforms['valid_test'])
+    train_loader = DataLoader(train_dataset, batch_size=CFG.train_bs, num_workers=0, shuffle=True, drop_last=False)
+    valid_loader = DataLoader(valid_dataset, batch_size=CFG.valid_bs, num_workers=0, shuffle=False)
+    return train_loader, valid_loader
+
+
+def deliver(source_dir="/app/train/new/", dest_dir_train="/app/train/new_train", dest_dir_val="/app/train/new_valid"):
+    """utils/trainClass.py:557-595: move image + xml pairs 80/20 (one random.random() per image after a shuffle of the
+    listing) into the train / valid folders; images without an xml are skipped with a warning."""
+    import shutil
+    os.makedirs(dest_dir_train, exist_ok=True)
+    os.makedirs(dest_dir_val, exist_ok=True)
+    filenames = [f for f in sorted(os.listdir(source_dir)) if f.endswith(('.jpg', '.jpeg', '.png'))]
+    random.shuffle(filenames)
+    for filename in filenames:
+        xml_name = os.path.splitext(filename)[0] + '.xml'
+        if not os.path.exists(os.path.join(source_dir, xml_name)):
+            print(f"Warning: XML file {os.path.join(source_dir, xml_name)} not found for image {filename}. Skipping.")
+            continue
+        dest = dest_dir_train if random.random() > 0.2 else dest_dir_val
+        try:
+            shutil.move(os.path.join(source_dir, filename), os.path.join(dest, filename))
+            shutil.move(os.path.join(source_dir, xml_name), os.path.join(dest, xml_name))
+        except Exception as e:
+            print(f"Error moving file {filename} or its XML: {e}")
+    print("Data delivery complete.")
+
+
+def classExport(CFG, pretrained=None, modelName=None):
+    """utils/trainClass.py:512-541 exports the classifier to ONNX for onnxruntime; neither exists on this path (the
+    trained state dict is what build_model loads): reported, not raised, like the reference's export errors."""
+    print("classExport: ONNX export is not part of the MI355X path; use the saved state dict with utils.utils.build_model")
+    return None
+
+
+def train(CFG, log=False, save_path="/app/utils/new_weight/best.pth"):
+    """utils/trainClass.py:424-508: datasets from CFG.train_path / CFG.valid_path, model from CFG.pretrained (random
+    init if that file is absent), CFG.epoch epochs of train_one_epoch + valid_one_epoch, best state dict to
+    /app/utils/new_weight/best.pth, result.json when `log`.  The stochastic training augmentations
+    (utils/trainClass.py:199-216) are not built: training crops get the random inflation of crop_image and the
+    deterministic resize + normalise."""
+    data_transforms = build_transforms(CFG)
+    objects, objects_circle = xml2pd(CFG.train_path)
+    valid_objects, valid_objects_circle = xml2pd(CFG.valid_path)
+    if not (objects or objects_circle):
+        raise yvhip.YvError(f"no annotated objects under {CFG.train_path}")
+    train_loader, valid_loader = build_dataloader(objects, objects_circle, valid_objects, valid_objects_circle, data_transforms)
+    pretrained = CFG.pretrained if CFG.pretrained and os.path.exists(CFG.pretrained) else None
+    if pretrained is None:
+        print(f"train: {CFG.pretrained} not found, seeded random initialisation")
+    if pretrained is None:
+        from yvhip.modules import create_model
+        net = Network_Wrapper(create_model(CFG.modelName, pretrained=False, num_classes=1000), CFG.num_classes)
+    else:
+        net = build_model(CFG, pretrained=pretrained)
+    net.to(CFG.device)
+    if save_path:
+        try:
+            os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        except OSError as e:
+            print(f"train: cannot create {os.path.dirname(save_path)}: {e}")
+            save_path = None
+    return fit(net, train_loader, valid_loader, CFG, log=log, save_path=save_path)
 
 
 def fit(net, train_loader, valid_loader, CFG, log=False, save_path=None):
@@ -281,11 +415,22 @@ def fit(net, train_loader, valid_loader, CFG, log=False, save_path=None):
 
 
 def retrain(log=False):
-    """app.py:91-94,181-184 call this on a background thread and ignore the return value; the reference
-    style is to report and return instead of raising."""
+    """utils/trainClass.py:598-640 (app.py:91-94,181-184 call this on a background thread and ignore the return value):
+    seed, deliver the new images 80/20, clear result.json, train, export.  Reference style: report and return."""
     try:
         set_seed(CFG.seed)
+        print("Starting data delivery...")
+        deliver()
+        if log:
+            try:
+                with open('/app/train/result.json', 'w') as f:
+                    json.dump({}, f)
+            except IOError:
+                print("Error: Could not clear /app/train/result.json for new training log.")
+        print("Starting training...")
         train(CFG, log)
+        classExport(CFG, pretrained="/app/utils/new_weight/best.pth")
+        print("Retraining process complete.")
     except Exception as e:
         print(f"retrain: {e}")
         return False
