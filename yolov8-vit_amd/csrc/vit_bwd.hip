@@ -68,9 +68,38 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
 }
 
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int parts, int cols,
-                                                          float* __restrict__ out, int accumulate) {
-    // 32 columns x 8 row-groups per workgroup; each group sums every 8th partial row (fixed order), then the 8 group
-    // sums are added in group order: deterministic, and 8x the parallelism of one thread per column
+                                                          float* __restrict__ out, int accumulate,
+                                                          float* __restrict__ out2 = nullptr, int split = 0) {
+    // 32 columns (8 float4 groups) x 32 row-groups per workgroup; each group sums every 32nd partial row (fixed order),
+    // then the 32 group sums are added in group order: deterministic.  cols is a multiple of 4 (host check).
+    __shared__ float4 red[32][8];
+    const int cg = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const int c = blockIdx.x * 32 + cg * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols)
+        for (int p = grp; p < parts; p += 32) {
+            const float4 v = *(const float4*)(partial + (long long)p * cols + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[grp][cg] = s;
+    __syncthreads();
+    if (grp == 0 && c < cols) {
+        float4 t = red[0][cg];
+#pragma unroll
+        for (int q = 1; q < 32; ++q) { t.x += red[q][cg].x; t.y += red[q][cg].y; t.z += red[q][cg].z; t.w += red[q][cg].w; }
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = c + i;
+            float* o = (out2 && ci >= split) ? out2 + (ci - split) : out + ci;      // [0, split) -> out, [split, cols) -> out2
+            *o = accumulate ? *o + tv[i] : tv[i];
+        }
+    }
+}
+
+// columns not a multiple of 4 (small heads): one column per thread, 8 row groups
+__global__ __launch_bounds__(256) void reduce_rows_scalar_kernel(const float* __restrict__ partial, int parts, int cols,
+                                                                 float* __restrict__ out, int accumulate) {
     __shared__ float red[8][32];
     const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -87,9 +116,19 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
+void launch_reduce_rows(hipStream_t st, const float* partial, int parts, int cols, float* out, int accumulate,
+                        float* out2 = nullptr, int split = 0) {
+    if ((cols & 3) == 0 && (((uintptr_t)partial) & 15) == 0)
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, partial, parts, cols, out, accumulate, out2,
+                           split);
+    else
+        hipLaunchKernelGGL(reduce_rows_scalar_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, partial, parts, cols, out,
+                           accumulate);
+}
+
 // ---------------------------------------------------------------------------------------- LayerNorm backward
 constexpr int LNB_MAXC = 4;
-constexpr int LNB_ROWS = 32;          // rows per workgroup (8 per wave)
+constexpr int LNB_ROWS = 8;           // rows per workgroup (2 per wave): 6304 tokens -> 788 workgroups (32 rows left 59 CUs idle)
 
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long long ldx,
                                                             const float* __restrict__ gamma,
@@ -290,8 +329,7 @@ extern "C" int yv_cast_colsum(const float* x, int rows, int cols, void* y_bf16, 
     hipLaunchKernelGGL(cast_colsum_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, x, rows, cols,
                        (uint16_t*)y_bf16, colsum ? ws : nullptr, CS_ROWS);
     if (colsum)
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, ws, parts, cols, colsum,
-                           accumulate);
+        launch_reduce_rows(st, ws, parts, cols, colsum, accumulate);
     return yv_launch_status();
 }
 
@@ -302,8 +340,7 @@ extern "C" int yv_colsum_bf16(const void* x, int rows, int cols, long long ld, f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, (const uint16_t*)x, rows,
                        cols, ld, ws, CS_ROWS);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, ws, parts, cols, colsum,
-                       accumulate);
+    launch_reduce_rows(st, ws, parts, cols, colsum, accumulate);
     return yv_launch_status();
 }
 
@@ -322,10 +359,7 @@ extern "C" int yv_layernorm_bwd(const float* x, long long ldx, const float* gamm
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, gamma, (const uint16_t*)dy, lddy,
                        rows, D, eps, dx, lddx, ws);
     // partial layout [block][2][D]: reduce with stride 2*D -> view as `blocks` rows of 2*D columns
-    float* tmp = ws + (size_t)blocks * 2 * D;          // the last 2*D floats of the workspace
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, st, ws, blocks, 2 * D, tmp, 0);
-    (void)hipMemcpyAsync(dgamma, tmp, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(dbeta, tmp + D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
+    launch_reduce_rows(st, ws, blocks, 2 * D, dgamma, 0, dbeta, D);
     return yv_launch_status();
 }
 
