@@ -391,3 +391,33 @@ def test_training_steps_reduce_the_loss(yv):
     assert set(out) == set(sd)
     tr2 = YoloTrainer(out, scale=scale, nc=nc, size=S, batch=B)
     assert torch.equal(tr2.P.cpu(), tr.P.cpu())
+
+
+def test_trained_weights_fold_into_the_inference_engine(yv):
+    """Train a few steps, save, load through YOLOTensorRT.models.fold_batchnorm into the inference YoloEngine (BN folded
+    with the RUNNING statistics the trainer maintained) and compare its raw head outputs with the oracle's eval-mode
+    forward on the same state dict: closes the loop utils.trainYolo.train -> app.py inference.  Tolerance rel-L2 5e-2
+    (bf16 activations through 23 modules; eval-mode BN does not amplify like batch statistics do)."""
+    from oracle import yolo_train as oy
+    from YOLOTensorRT.models import fold_batchnorm
+    from yvhip import engines
+    from yvhip.yolo_training import YoloTrainer, init_yolo_train_state
+    scale, nc, S, B, G = "n", 5, 160, 4, 2
+    tr = YoloTrainer(init_yolo_train_state(scale, nc, seed=2), scale=scale, nc=nc, size=S, batch=B, lr=1e-3)
+    g = torch.Generator().manual_seed(8)
+    img = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
+    ctr = torch.rand(B, G, 2, generator=g) * 100 + 30
+    gtb = torch.cat([ctr - 20, ctr + 20], -1).to(DEV)
+    gtl = torch.randint(0, nc, (B, G), generator=g, dtype=torch.int32).to(DEV)
+    gtn = torch.full((B,), G, dtype=torch.int32, device=DEV)
+    for _ in range(40):                                   # momentum 0.03: running statistics need a few dozen updates
+        tr.step(img.to(DEV), gtb, gtl, gtn)
+    sd = tr.state_dict()
+    eng = engines.YoloEngine(fold_batchnorm(sd), scale, nc, S, device=DEV)
+    box_l, cls_l = eng.forward_raw(img.to(DEV))
+    torch.cuda.synchronize()
+    x = bf(img.float() * torch.tensor(1.0 / 255.0)).float().permute(0, 3, 1, 2).contiguous()
+    ref = oy.forward_train({k: v.clone() for k, v in sd.items()}, x, scale, nc, train=False)
+    for s, (rb, rc) in enumerate(ref):
+        assert rel_l2(box_l[s].float().cpu().permute(0, 3, 1, 2), rb) < 5e-2, s
+        assert rel_l2(cls_l[s].float().cpu().permute(0, 3, 1, 2)[:, :nc], rc) < 5e-2, s
