@@ -263,6 +263,19 @@ int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, f
 int yv_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum, float weight_decay,
                 float grad_scale, int first, void* bf16_mirror /* optional: bf16 copy of the updated p */, void* stream);
 
+/* Optimisers ultralytics builds for `optimizer='auto'` (the reference calls `.train(..., lr0=1e-4, lrf=1e-4)` with that
+ * default, utils/trainYolo.py:33), element-wise in the operation order of torch's single-tensor implementations:
+ * kind 1 = torch.optim.SGD(momentum=beta1, nesterov=True, weight_decay) (v unused), kind 2 = torch.optim.AdamW(betas,
+ * eps, weight_decay).  step counts from 1 (bias corrections; step 1 initialises the state).  g is scaled by grad_scale. */
+int yv_optim_step(int kind, float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float grad_scale, int step, void* bf16_mirror, void* stream);
+
+/* dst = a*dst + b*src (gradient accumulation over `accumulate` batches: a = b = 1). */
+int yv_axpby(float* dst, const float* src, size_t n, float a, float b, void* stream);
+
+/* ultralytics ModelEMA: ema = decay*ema + (1-decay)*src. */
+int yv_ema_update(float* ema, const float* src, size_t n, float decay, void* stream);
+
 /* ---- detector training (the ultralytics trainer behind utils/trainYolo.py:13-35) --------
  * Conv = conv(no bias) -> BatchNorm2d(eps 1e-3, momentum 0.03) -> SiLU, un-folded; activations are NHWC bf16 views:
  * (rows = B*H*W, C) with a row stride `ld` (elements), C a multiple of 8, pointers 16-byte aligned. */

@@ -194,14 +194,16 @@ def test_train_yolo_surface(tmp_path):
     logs = []
     res = ty.train(epochs=3, batch=2, data=str(tmp_path / "config.yaml"), size=128, save=str(tmp_path / "w" / "best.pth"),
                    log=logs.append)
-    assert len(res["epochs"]) == 3 and res["epochs"][0]["steps"] == n_train // 2 and "EMA" in res["not_built"]
+    assert len(res["epochs"]) == 3 and res["epochs"][0]["steps"] == n_train // 2 and any("val" in x for x in res["not_built"])
+    assert res["optimizer"] == "adamw" and res["lr0"] == pytest.approx(0.001111) and res["accumulate"] == 32   # optimizer=auto
     assert all(np.isfinite(e["loss"]) for e in res["epochs"])
-    assert res["epochs"][0]["lr"] == pytest.approx(1e-4) and res["epochs"][2]["lr"] < res["epochs"][1]["lr"]
+    assert res["epochs"][0]["lr"] == pytest.approx(0.001111) and res["epochs"][2]["lr"] < res["epochs"][1]["lr"]
     sd = torch.load(res["weights"], map_location="cpu", weights_only=True)
     assert "model.0.conv.weight" in sd and "model.22.cv3.2.2.bias" in sd and sd["model.0.bn.running_var"].shape == (16,)
     res2 = ty.train(epochs=1, batch=2, data=str(tmp_path / "config.yaml"), size=128, weights=res["weights"],
-                    save=str(tmp_path / "w" / "again.pth"), log=logs.append)
+                    save=str(tmp_path / "w" / "again.pth"), log=logs.append, optimizer="SGD", lr0=1e-4)
     assert res2["epochs"][0]["steps"] == n_train // 2 and not any("random initialisation" in l for l in logs[-2:])
+    assert res2["optimizer"] == "sgd_nesterov" and res2["lr0"] == 1e-4
 
 
 def test_train_class_from_xml_directories(tmp_path):

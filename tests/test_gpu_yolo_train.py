@@ -2,6 +2,8 @@
 CPU.  Parity UNPINNED against ultralytics (absent from the tree and the image): the reference here is the published
 layer definition (Conv = conv -> BatchNorm2d(eps 1e-3, momentum 0.03) -> SiLU) executed by torch on bf16-representable
 inputs; tolerances cover bf16 rounding of the outputs (2^-9 relative) and are written per test."""
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -421,3 +423,40 @@ def test_trained_weights_fold_into_the_inference_engine(yv):
     for s, (rb, rc) in enumerate(ref):
         assert rel_l2(box_l[s].float().cpu().permute(0, 3, 1, 2), rb) < 5e-2, s
         assert rel_l2(cls_l[s].float().cpu().permute(0, 3, 1, 2)[:, :nc], rc) < 5e-2, s
+
+
+@pytest.mark.parametrize("kind", ["sgd_nesterov", "adamw"])
+def test_optimisers_match_torch(yv, kind):
+    """yv_optim_step against torch.optim.SGD(nesterov=True) / torch.optim.AdamW on the CPU (the optimisers ultralytics
+    instantiates), 4 steps with changing lr; yv_ema_update against ModelEMA's rule.  fp32, same operation order:
+    max relative difference 1e-5 (torch's vectorised CPU kernels contract `p + alpha*g` into an FMA, the HIP build keeps
+    the two roundings: measured 3e-6)."""
+    g = torch.Generator().manual_seed(4)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (0.5 + i) for i in range(4)]
+    lrs = [1e-3, 2e-3, 5e-4, 1e-3]
+    ref = torch.nn.Parameter(p0.clone())
+    if kind == "adamw":
+        opt = torch.optim.AdamW([ref], lr=lrs[0], betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+        code, b1, wd = yv.OPT_ADAMW, 0.9, 5e-4
+    else:
+        opt = torch.optim.SGD([ref], lr=lrs[0], momentum=0.937, nesterov=True, weight_decay=5e-4)
+        code, b1, wd = yv.OPT_SGD_NESTEROV, 0.937, 5e-4
+    p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    mirror = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    ema_ref, ema = p0.clone(), p0.clone().to(DEV)
+    for t, (gr, lr) in enumerate(zip(grads, lrs), start=1):
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        ref.grad = gr.clone()
+        opt.step()
+        yv.optim_step(code, p, gr.to(DEV), m, v, lr, t, beta1=b1, weight_decay=wd, mirror=mirror)
+        d = 0.9999 * (1 - math.exp(-t / 2000))
+        ema_ref.mul_(d).add_((1 - d) * ref.detach())
+        yv.ema_update(ema, p, d)
+    torch.cuda.synchronize()
+    err = float(((p.cpu() - ref.detach()).abs() / (ref.detach().abs() + 1e-3)).max())
+    assert err < 1e-5, err
+    assert torch.equal(mirror.cpu(), p.cpu().to(torch.bfloat16))
+    assert torch.allclose(ema.cpu(), ema_ref, rtol=1e-6, atol=1e-7)

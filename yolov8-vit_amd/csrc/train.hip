@@ -79,7 +79,77 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
 }
 
+// Optimisers of the detector trainer (what ultralytics builds for `optimizer='auto'`: torch.optim.AdamW for short runs,
+// torch.optim.SGD(nesterov=True) for long ones) + the ModelEMA update.  One element per thread, explicit _rn ops in the
+// operation order of torch's single-tensor implementations.
+//   kind 1 SGD-Nesterov: g += wd*p; buf = first ? g : mu*buf + g; p -= lr*(g + mu*buf)
+//   kind 2 AdamW:        p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+//                        p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void optim_kernel(int kind, float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, size_t n, float lr, float b1,
+                                                    float b2, float eps, float wd, float gs, float decay_mul, float om_b1,
+                                                    float om_b2, float step_size, float sqrt_bc2, int first,
+                                                    uint16_t* __restrict__ mirror) {
+    // decay_mul = 1 - lr*wd, om_b* = 1 - beta*, step_size = lr / (1 - beta1^t), sqrt_bc2 = sqrt(1 - beta2^t): evaluated in
+    // double on the host and rounded once, as torch's Python scalars are
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float pe = p[i];
+        float ge = gs == 1.0f ? g[i] : __fmul_rn(g[i], gs);
+        if (kind == 1) {
+            ge = __fadd_rn(ge, __fmul_rn(wd, pe));
+            const float buf = first ? ge : __fadd_rn(__fmul_rn(b1, m[i]), ge);
+            m[i] = buf;
+            pe = __fsub_rn(pe, __fmul_rn(lr, __fadd_rn(ge, __fmul_rn(b1, buf))));
+        } else {
+            pe = __fmul_rn(pe, decay_mul);
+            const float mo = first ? 0.f : m[i], vo = first ? 0.f : v[i];
+            const float mn = __fadd_rn(mo, __fmul_rn(om_b1, __fsub_rn(ge, mo)));                       // exp_avg.lerp_(grad, 1 - b1)
+            const float vn = __fadd_rn(__fmul_rn(vo, b2), __fmul_rn(__fmul_rn(om_b2, ge), ge));       // mul_(b2).addcmul_(g, g, 1 - b2)
+            m[i] = mn; v[i] = vn;
+            const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vn), sqrt_bc2), eps);
+            pe = __fsub_rn(pe, __fmul_rn(step_size, __fdiv_rn(mn, denom)));                             // addcdiv_(m, denom, -step_size)
+        }
+        p[i] = pe;
+        if (mirror) mirror[i] = f32_to_bf16(pe);
+    }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n, float a,
+                                                    float b) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = __fadd_rn(__fmul_rn(dst[i], a), __fmul_rn(b, src[i]));            // ModelEMA: v *= d; v += (1 - d) * model
+}
+
 }  // namespace
+
+extern "C" int yv_optim_step(int kind, float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float grad_scale, int step, void* bf16_mirror,
+                             void* stream) {
+    if (!(kind == 1 || kind == 2) || !p || !g || !m || (kind == 2 && !v) || step < 1) return YV_ERR_ARG;
+    if (n == 0) return YV_OK;
+    const size_t want = (n + 255) / 256;
+    const int blocks = (int)(want > 4096 ? 4096 : want);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(optim_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, kind, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, grad_scale, (float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1),
+                       (float)(1.0 - (double)beta2), (float)((double)lr / bc1), (float)sqrt(bc2), step == 1 ? 1 : 0,
+                       (uint16_t*)bf16_mirror);
+    return yv_launch_status();
+}
+
+extern "C" int yv_axpby(float* dst, const float* src, size_t n, float a, float b, void* stream) {
+    if (!dst || !src) return YV_ERR_ARG;
+    if (n == 0) return YV_OK;
+    const size_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(axpby_kernel, dim3((int)(want > 4096 ? 4096 : want)), dim3(256), 0, (hipStream_t)stream, dst, src, n, a, b);
+    return yv_launch_status();
+}
+
+extern "C" int yv_ema_update(float* ema, const float* src, size_t n, float decay, void* stream) {
+    return yv_axpby(ema, src, n, decay, (float)(1.0 - (double)decay), stream);
+}
 
 extern "C" int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, float w_lsce, float w_focal,
                                float* loss, float* grad, void* stream) {

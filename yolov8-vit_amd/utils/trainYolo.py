@@ -3,9 +3,9 @@
 `train(epochs, batch, data)` keeps the reference's signature and runs the MI355X detector training step
 (yvhip.yolo_training.YoloTrainer: un-fused YOLOv8 forward with BatchNorm batch statistics, v8 detection loss,
 backward, SGD) over the YOLO-format dataset the `data` yaml names.  What `ultralytics` adds around that step is NOT
-built and is reported by `train()` in its result: the pre-training `model.val` mAP pass, mosaic / HSV / flip
-augmentation, EMA, warm-up, the AdamW choice of `optimizer='auto'`; the pickled `/app/utils/weight/best.pt` cannot be
-read with a safe loader, so initial weights come from `weights=` (a state dict written by this trainer) or from a
+built and is reported by `train()` in its result: the pre-training `model.val` mAP pass and the mosaic / HSV / flip
+augmentation; `optimizer='auto'` (AdamW / Nesterov SGD), warm-up, nominal-batch accumulation and ModelEMA follow the
+published trainer.  The pickled `/app/utils/weight/best.pt` cannot be read with a safe loader, so initial weights come from `weights=` (a state dict written by this trainer) or from a
 seeded random initialisation.  Parity unpinned: every piece lives in `ultralytics`, absent from the reference tree.
 """
 import json
@@ -19,12 +19,28 @@ from .class_config import xml2txt          # noqa: F401  (same import as the ref
 
 WEIGHTS_IN = "/app/utils/weight/best.pth"
 WEIGHTS_OUT = "/app/utils/new_weight/yolo_best.pth"
-NOT_BUILT = ["model.val (mAP) before training", "mosaic/HSV/flip augmentation", "EMA", "warm-up", "AdamW (optimizer='auto')"]
+NOT_BUILT = ["model.val (mAP) before training", "mosaic/HSV/flip augmentation"]
+NBS = 64                                   # ultralytics nominal batch size
 
 
-def train(epochs, batch, data, weights=None, scale="n", size=640, save=None, device="cuda:0", seed=42, log=print):
-    """utils/trainYolo.py:6-35: `model.train(epochs=, batch=, data=, lr0=1e-4, lrf=1e-4)`.
+def _auto_optimizer(n_images, batch, epochs, nc, lr0, momentum):
+    """ultralytics `optimizer='auto'`: more than 10000 iterations -> SGD(lr0 0.01, nesterov), else AdamW with
+    lr0 = round(0.002 * 5 / (4 + nc), 6); momentum 0.9 either way and the caller's lr0 / momentum are ignored."""
+    iterations = -(-n_images // max(batch, NBS)) * epochs
+    if iterations > 10000:
+        return "sgd_nesterov", 0.01, 0.9
+    return "adamw", round(0.002 * 5 / (4 + nc), 6), 0.9
+
+
+def train(epochs, batch, data, weights=None, scale="n", size=640, save=None, device="cuda:0", seed=42, log=print,
+          optimizer="auto", lr0=1e-4, lrf=1e-4, momentum=0.937, weight_decay=5e-4, warmup_epochs=3.0):
+    """utils/trainYolo.py:6-35: `model.train(epochs=, batch=, data=, lr0=1e-4, lrf=1e-4)` with the ultralytics defaults
+    around it: optimizer 'auto' (see _auto_optimizer), linear lr0 -> lr0*lrf schedule, warm-up over
+    max(3 epochs, 100 iterations) (lr from 0 - biases from 0.1, 0.0 under AdamW - and momentum from 0.8), gradient
+    accumulation to the nominal batch 64 with weight decay scaled by batch*accumulate/64, ModelEMA(0.9999, tau 2000)
+    whose weights are the ones saved.
     Returns {"epochs": [...per-epoch mean (total, box, cls, dfl)...], "weights": path or None, "not_built": [...]}."""
+    import numpy as np
     from yvhip.yolo_data import list_samples, load_batch, max_boxes_per_image, read_data_yaml
     from yvhip.yolo_training import YoloTrainer, init_yolo_train_state
     yvhip.require_gpu()
@@ -40,31 +56,49 @@ def train(epochs, batch, data, weights=None, scale="n", size=640, save=None, dev
     else:
         log(f"trainYolo.train: no readable initial weights, seeded random initialisation (seed {seed})")
         state = init_yolo_train_state(scale, nc, seed)
-    lr0, lrf = 1e-4, 1e-4
-    # ultralytics: weight decay scaled by batch * accumulate / 64 with accumulate = max(round(64 / batch), 1)
-    wd = 5e-4 * B * max(round(64 / B), 1) / 64
-    tr = YoloTrainer(state, scale=scale, nc=nc, size=size, batch=B, lr=lr0, momentum=0.937, weight_decay=wd, device=device)
+    opt, warmup_bias_lr = optimizer.lower(), 0.1
+    if opt == "auto":
+        opt, lr0, momentum = _auto_optimizer(len(samples), B, int(epochs), nc, lr0, momentum)
+        warmup_bias_lr = 0.0 if opt == "adamw" else 0.1
+        log(f"trainYolo.train: optimizer=auto -> {opt}, lr0={lr0}, momentum={momentum} (lr0/momentum arguments ignored, as ultralytics does)")
+    elif opt == "sgd":
+        opt = "sgd_nesterov"                                   # ultralytics builds SGD with nesterov=True
+    accumulate = max(round(NBS / B), 1)
+    wd = weight_decay * B * accumulate / NBS
+    tr = YoloTrainer(state, scale=scale, nc=nc, size=size, batch=B, lr=lr0, momentum=momentum, weight_decay=wd, device=device,
+                     optimizer=opt, ema=True)
     G = max_boxes_per_image(samples)
-    hist = []
+    nb = max(len(samples) // B, 1)                             # batches per epoch (last short batch dropped)
+    nw = max(round(warmup_epochs * nb), 100) if warmup_epochs > 0 else -1
+    lf = lambda ep: max(1 - ep / max(int(epochs), 1), 0) * (1.0 - lrf) + lrf
+    hist, ni = [], 0
     for ep in range(int(epochs)):
-        lr = lr0 * ((1 - ep / max(int(epochs), 1)) * (1.0 - lrf) + lrf)            # linear lr0 -> lr0*lrf
+        lr = lr0 * lf(ep)
         acc, steps = torch.zeros(4), 0
         for i in range(0, len(samples) - B + 1, B):
+            lrs, mom, acc_now = None, None, accumulate
+            if ni <= nw:                                       # warm-up (ultralytics trainer, per iteration)
+                xi = [0, nw]
+                acc_now = max(1, int(np.interp(ni, xi, [1, NBS / B]).round()))
+                lrs = {g: float(np.interp(ni, xi, [warmup_bias_lr if g == "bias" else 0.0, lr])) for g in ("w", "bnw", "bias")}
+                mom = float(np.interp(ni, xi, [0.8, momentum]))
             img, gtb, gtl, gtn = load_batch(samples[i:i + B], size, G)
-            loss = tr.step(img.to(device), gtb.to(device), gtl.to(device), gtn.to(device), lr)
+            loss = tr.step(img.to(device), gtb.to(device), gtl.to(device), gtn.to(device), lr, accumulate=acc_now, lrs=lrs,
+                           momentum=mom)
             acc += loss.cpu()
             steps += 1
+            ni += 1
         mean = (acc / max(steps, 1)).tolist()
         hist.append({"epoch": ep, "lr": lr, "loss": mean[0], "box": mean[1], "cls": mean[2], "dfl": mean[3], "steps": steps})
         log(f"epoch {ep}: loss {mean[0]:.4f} box {mean[1]:.4f} cls {mean[2]:.4f} dfl {mean[3]:.4f} ({steps} steps, lr {lr:.3g})")
     out = save if save is not None else WEIGHTS_OUT
     try:
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        torch.save(tr.state_dict(), out)
+        torch.save(tr.state_dict(ema=True), out)
     except OSError as e:
         log(f"trainYolo.train: cannot write {out}: {e}")
         out = None
-    return {"epochs": hist, "weights": out, "not_built": NOT_BUILT}
+    return {"epochs": hist, "weights": out, "not_built": NOT_BUILT, "optimizer": opt, "lr0": lr0, "accumulate": accumulate}
 
 
 def yoloRetrain():

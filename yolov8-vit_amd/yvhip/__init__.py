@@ -54,6 +54,9 @@ _SIGS = {
     "yv_crop_resize_norm": (_i, [_vp, _i, _i, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "yv_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "yv_optim_step": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
+    "yv_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
+    "yv_axpby": (_i, [_vp, _vp, _sz, _f, _f, _vp]),
     "yv_detect_loss_ws_bytes": (_sz, [_i, _i, _i]),
     "yv_detect_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _sz, _vp]),
     "yv_blob_nhwc8": (_i, [_vp, C.c_longlong, _vp, _vp]),
@@ -592,3 +595,25 @@ def detect_loss(box, cls, dbox, dcls, B: int, size: int, nc: int, ncp: int, gt_b
     check(lib.yv_detect_loss(arr(box), arr(cls), arr(dbox), arr(dcls), B, size, nc, ncp, _p(gt_boxes), _p(gt_labels),
                              _p(gt_counts), G, gains[0], gains[1], gains[2], _p(loss), _p(ws), ws.numel() * ws.element_size(),
                              _st()), "yv_detect_loss")
+
+
+OPT_SGD_NESTEROV, OPT_ADAMW = 1, 2
+
+
+def optim_step(kind: int, p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: Optional[torch.Tensor], lr: float, step: int,
+               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0, grad_scale: float = 1.0,
+               mirror: Optional[torch.Tensor] = None):
+    """torch.optim.SGD(nesterov=True) (kind 1) / torch.optim.AdamW (kind 2) on flat fp32 buffers; step counts from 1."""
+    _chk_dev(p, g, m, v, mirror)
+    check(lib.yv_optim_step(kind, _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                            float(weight_decay), float(grad_scale), int(step), _p(mirror), _st()), "yv_optim_step")
+
+
+def ema_update(ema: torch.Tensor, src: torch.Tensor, decay: float):
+    _chk_dev(ema, src)
+    check(lib.yv_ema_update(_p(ema), _p(src), ema.numel(), float(decay), _st()), "yv_ema_update")
+
+
+def axpby(dst: torch.Tensor, src: torch.Tensor, a: float, b: float):
+    _chk_dev(dst, src)
+    check(lib.yv_axpby(_p(dst), _p(src), dst.numel(), float(a), float(b), _st()), "yv_axpby")

@@ -19,7 +19,8 @@ import torch
 
 import math
 
-from . import (VIEW_ADD, VIEW_COPY, VIEW_UP2, VIEW_UP2_BWD, VIEW_ZERO_INSERT, YvError, blob_nhwc8, bn_act_bwd, bn_act_fwd,
+from . import (OPT_ADAMW, OPT_SGD_NESTEROV, VIEW_ADD, VIEW_COPY, VIEW_UP2, VIEW_UP2_BWD, VIEW_ZERO_INSERT, YvError, axpby,
+               blob_nhwc8, bn_act_bwd, bn_act_fwd, ema_update, optim_step,
                bn_stats, bn_ws_floats, cast_colsum, colsum_ws_floats, conv_view, conv_weight_dgrad, detect_loss,
                detect_loss_ws_bytes, im2col3, maxpool5_bwd, mview, require_gpu, sgd_step, sppf_pool, view_op, wgrad)
 from .engines import LAYER_STRIDE, REG_MAX, _c, yolo_conv_keys, yolo_layers
@@ -82,22 +83,26 @@ class _Block:
         self.cout_real = cout if cout_real is None else cout_real
         self.taps = k * k
         self.w = tr._param(key + (".conv.weight" if bn else ".weight"), cout * self.taps * cin, "w")
-        if bn:
-            self.gamma = tr._param(key + ".bn.weight", cout, "o")
-            self.beta = tr._param(key + ".bn.bias", cout, "o")
+        if bn:                                   # ultralytics groups: conv weights (decay) / BatchNorm weights / all biases
+            self.gamma = tr._param(key + ".bn.weight", cout, "bnw")
+            self.beta = tr._param(key + ".bn.bias", cout, "bias")
         else:
-            self.bias = tr._param(key + ".bias", cout, "o")
+            self.bias = tr._param(key + ".bias", cout, "bias")
         tr.blocks.append(self)
 
 
 class YoloTrainer:
     def __init__(self, state: Dict[str, torch.Tensor], scale: str = "n", nc: int = 5, size: int = 640, batch: int = 16,
-                 lr: float = 1e-4, momentum: float = 0.937, weight_decay: float = 5e-4, device: str = "cuda:0"):
+                 lr: float = 1e-4, momentum: float = 0.937, weight_decay: float = 5e-4, device: str = "cuda:0",
+                 optimizer: str = "sgd", ema: bool = False, ema_decay: float = 0.9999, ema_tau: float = 2000.0):
         require_gpu()
         if size % 32:
             raise YvError("input size must be a multiple of 32")
         self.scale, self.nc, self.size, self.B, self.dev = scale, nc, size, batch, torch.device(device)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        if optimizer not in ("sgd", "sgd_nesterov", "adamw"):
+            raise YvError("optimizer must be 'sgd', 'sgd_nesterov' or 'adamw'")
+        self.optimizer, self.use_ema, self.ema_decay, self.ema_tau = optimizer, ema, ema_decay, ema_tau
         self.ncp = (nc + 7) // 8 * 8
         self.blocks: List[_Block] = []
         self._pspecs: List[Tuple[str, int, str]] = []
@@ -117,15 +122,18 @@ class YoloTrainer:
         return len(self._pspecs) - 1
 
     def _alloc_params(self, state: Dict[str, torch.Tensor]):
-        order = [i for i, s in enumerate(self._pspecs) if s[2] == "w"] + [i for i, s in enumerate(self._pspecs) if s[2] == "o"]
+        order = [i for g in ("w", "bnw", "bias") for i, s in enumerate(self._pspecs) if s[2] == g]
         self.off: Dict[int, Tuple[int, int]] = {}
+        self.group: Dict[str, Tuple[int, int]] = {}
         pos = 0
         for i in order:
             n = (self._pspecs[i][1] + 7) // 8 * 8            # 32-byte aligned segments
             self.off[i] = (pos, self._pspecs[i][1])
+            g = self._pspecs[i][2]
+            lo = self.group[g][0] if g in self.group else pos
             pos += n
-            if self._pspecs[i][2] == "w":
-                self.n_weight = pos
+            self.group[g] = (lo, pos)
+        self.n_weight = self.group["w"][1]
         self.n_param = pos
         host = torch.zeros(pos, dtype=torch.float32)
         for b in self.blocks:
@@ -148,12 +156,26 @@ class YoloTrainer:
         self.G = torch.zeros_like(self.P)
         self.Mo = torch.zeros_like(self.P)
         self.P16 = self.P[:self.n_weight].to(torch.bfloat16)
-        self.run_mean: Dict[str, torch.Tensor] = {}
-        self.run_var: Dict[str, torch.Tensor] = {}
+        self.V: Optional[torch.Tensor] = None                     # AdamW second moments (allocated on first use)
+        # running statistics: one flat buffer (mean | var per block) so the EMA is a single launch
+        n_rs = sum(2 * b.cout for b in self.blocks if b.bn)
+        rs_host = torch.zeros(n_rs)
+        self._rs_off: Dict[str, int] = {}
+        pos = 0
         for b in self.blocks:
             if b.bn:
-                self.run_mean[b.key] = state[b.key + ".bn.running_mean"].float().to(self.dev).contiguous()
-                self.run_var[b.key] = state[b.key + ".bn.running_var"].float().to(self.dev).contiguous()
+                self._rs_off[b.key] = pos
+                rs_host[pos:pos + b.cout] = state[b.key + ".bn.running_mean"].float()
+                rs_host[pos + b.cout:pos + 2 * b.cout] = state[b.key + ".bn.running_var"].float()
+                pos += 2 * b.cout
+        self.RS = rs_host.to(self.dev)
+        self.run_mean = {b.key: self.RS[self._rs_off[b.key]:self._rs_off[b.key] + b.cout] for b in self.blocks if b.bn}
+        self.run_var = {b.key: self.RS[self._rs_off[b.key] + b.cout:self._rs_off[b.key] + 2 * b.cout] for b in self.blocks if b.bn}
+        self.P_ema = self.P.clone() if self.use_ema else None
+        self.RS_ema = self.RS.clone() if self.use_ema else None
+        self.ema_updates = 0
+        self.G_acc: Optional[torch.Tensor] = None
+        self.accumulated = 0
 
     def p(self, pid: int) -> torch.Tensor:
         o, n = self.off[pid]
@@ -167,10 +189,13 @@ class YoloTrainer:
         o, n = self.off[b.w]
         return self.P16[o:o + n]
 
-    def state_dict(self) -> Dict[str, torch.Tensor]:
-        """Un-fused ultralytics key layout, fp32, on the host."""
+    def state_dict(self, ema: bool = False) -> Dict[str, torch.Tensor]:
+        """Un-fused ultralytics key layout, fp32, on the host; ema=True returns the ModelEMA copy (what ultralytics saves)."""
         sd: Dict[str, torch.Tensor] = {}
-        P = self.P.cpu()
+        if ema and not self.use_ema:
+            raise YvError("trainer was built without ema=True")
+        P = (self.P_ema if ema else self.P).cpu()
+        RS = (self.RS_ema if ema else self.RS).cpu()
         for b in self.blocks:
             o, n = self.off[b.w]
             w = P[o:o + n].view(b.cout, b.k, b.k, b.cin)[:b.cout_real, :, :, :b.cin_real].permute(0, 3, 1, 2).contiguous()
@@ -179,8 +204,9 @@ class YoloTrainer:
                 for pid, suffix in ((b.gamma, ".bn.weight"), (b.beta, ".bn.bias")):
                     o2, n2 = self.off[pid]
                     sd[b.key + suffix] = P[o2:o2 + n2].clone()
-                sd[b.key + ".bn.running_mean"] = self.run_mean[b.key].cpu()
-                sd[b.key + ".bn.running_var"] = self.run_var[b.key].cpu()
+                ro = self._rs_off[b.key]
+                sd[b.key + ".bn.running_mean"] = RS[ro:ro + b.cout].clone()
+                sd[b.key + ".bn.running_var"] = RS[ro + b.cout:ro + 2 * b.cout].clone()
             else:
                 sd[b.key + ".weight"] = w
                 o2, _ = self.off[b.bias]
@@ -482,24 +508,58 @@ class YoloTrainer:
         return self.loss_out
 
     def step(self, images: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torch.Tensor, gt_counts: torch.Tensor,
-             lr: Optional[float] = None):
-        """forward -> loss -> backward -> (data-parallel SUM all-reduce, mean folded into the update) -> SGD."""
+             lr: Optional[float] = None, accumulate: int = 1, lrs: Optional[Dict[str, float]] = None,
+             momentum: Optional[float] = None):
+        """forward -> loss -> backward -> [every `accumulate` calls: data-parallel SUM all-reduce (mean folded into the
+        update) -> optimiser -> EMA].  `lrs` gives per-group learning rates ({'w','bnw','bias'}: warm-up treats biases
+        differently), `momentum` overrides momentum / beta1 for this step."""
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.forward(images)
         loss = self.loss(gt_boxes, gt_labels, gt_counts)
-        self.reducer.reset()
         self.backward()
+        if accumulate > 1:
+            if self.G_acc is None:
+                self.G_acc = torch.zeros_like(self.G)
+            if self.accumulated == 0:
+                self.G_acc.copy_(self.G)
+            else:
+                axpby(self.G_acc, self.G, 1.0, 1.0)
+            self.accumulated += 1
+            if self.accumulated < accumulate:
+                return loss
+            self.G.copy_(self.G_acc)
+            self.accumulated = 0
+        self.reducer.reset()
         self.reducer.finish()
-        self.optimizer_step(lr, grad_scale=1.0 / world)
+        self.optimizer_step(lr, grad_scale=1.0 / world, lrs=lrs, momentum=momentum)
         return loss
 
     # ------------------------------------------------------------------ optimiser
-    def optimizer_step(self, lr: Optional[float] = None, grad_scale: float = 1.0):
-        """SGD(momentum) with weight decay on the conv weights only (ultralytics: no decay on BatchNorm / biases)."""
+    def optimizer_step(self, lr: Optional[float] = None, grad_scale: float = 1.0, lrs: Optional[Dict[str, float]] = None,
+                       momentum: Optional[float] = None):
+        """One update of every parameter group (ultralytics: weight decay on conv weights only; BatchNorm weights and
+        all biases undecayed) with torch.optim.SGD / SGD(nesterov) / AdamW semantics, then the ModelEMA update."""
         lr = self.lr if lr is None else lr
-        first = self.step_count == 0
-        nw = self.n_weight
-        sgd_step(self.P[:nw], self.G[:nw], self.Mo[:nw], lr, self.momentum, self.weight_decay, first, grad_scale, mirror=self.P16)
-        sgd_step(self.P[nw:], self.G[nw:], self.Mo[nw:], lr, self.momentum, 0.0, first, grad_scale)
+        mom = self.momentum if momentum is None else momentum
         self.step_count += 1
+        t = self.step_count
+        for g, wd in (("w", self.weight_decay), ("bnw", 0.0), ("bias", 0.0)):
+            lo, hi = self.group[g]
+            if hi <= lo:
+                continue
+            glr = lrs[g] if lrs is not None and g in lrs else lr
+            mirror = self.P16 if g == "w" else None
+            if self.optimizer == "sgd":
+                sgd_step(self.P[lo:hi], self.G[lo:hi], self.Mo[lo:hi], glr, mom, wd, t == 1, grad_scale, mirror=mirror)
+            else:
+                if self.optimizer == "adamw" and self.V is None:
+                    self.V = torch.zeros_like(self.P)
+                optim_step(OPT_ADAMW if self.optimizer == "adamw" else OPT_SGD_NESTEROV, self.P[lo:hi], self.G[lo:hi],
+                           self.Mo[lo:hi], self.V[lo:hi] if self.V is not None else None, glr, t, beta1=mom, weight_decay=wd,
+                           grad_scale=grad_scale, mirror=mirror)
+        if self.use_ema:
+            self.ema_updates += 1
+            d = self.ema_decay * (1.0 - math.exp(-self.ema_updates / self.ema_tau))
+            ema_update(self.P_ema, self.P, d)
+            ema_update(self.RS_ema, self.RS, d)
