@@ -232,3 +232,35 @@ def test_yolo_dataset_reader(tmp_path):
     assert np.allclose(gtb[1, 0].numpy(), [24.0, 24.0, 40.0, 40.0]) and gtl[1].tolist() == [1, 3]
     lb, r, (left, top) = letterbox_host(np.zeros((40, 80, 3), np.uint8), 64)
     assert (r, left, top) == (0.8, 0, 16) and lb[0, 0, 0] == 114 and lb[16, 0, 0] == 0 and lb[47, 0, 0] == 0 and lb[48, 0, 0] == 114
+
+
+def test_detection_metrics_hand_cases():
+    """yvhip/yolo_val.py (host bookkeeping of `model.val`, utils/trainYolo.py:21-26) on cases with known answers."""
+    from yvhip.yolo_val import IOUV, ap_per_class, box_iou_np, compute_ap, match_predictions
+    gt = np.array([[0, 0, 10, 10], [20, 20, 40, 40]], float)
+    pr = np.array([[0, 0, 10, 10], [20, 20, 40, 36.4], [100, 100, 110, 110]], float)    # exact, IoU 0.82, miss
+    iou = box_iou_np(gt, pr)
+    assert np.allclose(iou[0, 0], 1.0) and np.allclose(iou[1, 1], 0.82, atol=1e-6) and iou[0, 2] == 0
+    c = match_predictions(np.array([0, 1, 1]), np.array([0, 1]), iou)
+    assert c[0].all() and c[1].tolist() == [t < 0.81 for t in IOUV] and not c[2].any()
+    wrong_class = match_predictions(np.array([1, 1, 1]), np.array([0, 1]), iou)
+    assert not wrong_class[0].any()
+    # two predictions on one ground truth: one match per threshold; as published, after the unique-by-prediction step the
+    # candidates are in prediction (= confidence) order, so the earlier prediction keeps the match wherever it qualifies
+    dup = match_predictions(np.array([0, 0]), np.array([0]), box_iou_np(gt[:1], np.array([[0, 0, 10, 9.2], [0, 0, 10, 10]], float)))
+    assert dup[0].tolist() == [True] * 9 + [False] and dup[1].tolist() == [False] * 9 + [True]
+    # AP: all correct -> 0.995 (the published 101-point rule interpolates the closing sentinel (1, 0) at x = 1: the
+    # well-known ceiling of ultralytics' mAP); TP, FP, TP over 2 ground truths: recall .5,.5,1 precision 1,.5,.667
+    assert abs(compute_ap(np.array([0.5, 1.0]), np.array([1.0, 1.0])) - 0.995) < 1e-9
+    ap = compute_ap(np.array([0.5, 0.5, 1.0]), np.array([1.0, 0.5, 2 / 3]))
+    x = np.linspace(0, 1, 101)
+    env = np.where(x <= 0.5, 1.0, 2 / 3)
+    env[-1] = 0.0
+    assert abs(ap - float(np.sum((env[1:] + env[:-1]) * 0.5 * np.diff(x)))) < 4e-3
+    tp = np.zeros((3, 10), bool); tp[0] = True; tp[2] = True
+    res = ap_per_class(tp, np.array([0.9, 0.8, 0.7]), np.array([0, 0, 0]), np.array([0, 0]))
+    assert abs(res["map50"] - ap) < 1e-9 and abs(res["map"] - ap) < 1e-9 and res["classes"].tolist() == [0]
+    res2 = ap_per_class(np.ones((2, 10), bool), np.array([0.9, 0.8]), np.array([0, 1]), np.array([0, 1, 2]))
+    assert res2["ap"].shape == (3, 10) and abs(res2["map50"] - 2 * 0.995 / 3) < 1e-9   # class 2 never predicted: AP 0
+    empty = ap_per_class(np.zeros((0, 10), bool), np.zeros(0), np.zeros(0), np.array([0, 1]))
+    assert empty["map"] == 0.0

@@ -3,8 +3,8 @@
 `train(epochs, batch, data)` keeps the reference's signature and runs the MI355X detector training step
 (yvhip.yolo_training.YoloTrainer: un-fused YOLOv8 forward with BatchNorm batch statistics, v8 detection loss,
 backward, SGD) over the YOLO-format dataset the `data` yaml names.  What `ultralytics` adds around that step is NOT
-built and is reported by `train()` in its result: the pre-training `model.val` mAP pass and the mosaic / HSV / flip
-augmentation; `optimizer='auto'` (AdamW / Nesterov SGD), warm-up, nominal-batch accumulation and ModelEMA follow the
+built and is reported by `train()` in its result: the mosaic / HSV / flip augmentation and the per-epoch validation
+with best-fitness checkpoint selection (metrics are computed before and after training, `val()`); `optimizer='auto'` (AdamW / Nesterov SGD), warm-up, nominal-batch accumulation and ModelEMA follow the
 published trainer.  The pickled `/app/utils/weight/best.pt` cannot be read with a safe loader, so initial weights come from `weights=` (a state dict written by this trainer) or from a
 seeded random initialisation.  Parity unpinned: every piece lives in `ultralytics`, absent from the reference tree.
 """
@@ -19,7 +19,7 @@ from .class_config import xml2txt          # noqa: F401  (same import as the ref
 
 WEIGHTS_IN = "/app/utils/weight/best.pth"
 WEIGHTS_OUT = "/app/utils/new_weight/yolo_best.pth"
-NOT_BUILT = ["model.val (mAP) before training", "mosaic/HSV/flip augmentation"]
+NOT_BUILT = ["mosaic/HSV/flip augmentation", "per-epoch validation / best-fitness checkpoint selection"]
 NBS = 64                                   # ultralytics nominal batch size
 
 
@@ -30,6 +30,16 @@ def _auto_optimizer(n_images, batch, epochs, nc, lr0, momentum):
     if iterations > 10000:
         return "sgd_nesterov", 0.01, 0.9
     return "adamw", round(0.002 * 5 / (4 + nc), 6), 0.9
+
+
+def val(state, data, scale="n", imgsz=640, batch=16, conf=0.25, iou=0.6, device="cuda:0"):
+    """`model.val(data=, imgsz=640, batch=16, conf=0.25, iou=0.6, device='0')` (utils/trainYolo.py:21-26): detection
+    metrics of a state dict over the yaml's `val` split (yvhip/yolo_val.py)."""
+    from yvhip.yolo_data import list_samples, read_data_yaml
+    from yvhip.yolo_val import validate
+    cfg = read_data_yaml(data)
+    samples = list_samples(cfg["val"]) if cfg["val"] and os.path.isdir(cfg["val"]) else []
+    return validate(state, samples, scale, cfg["nc"], imgsz, batch, conf, iou, device)
 
 
 def train(epochs, batch, data, weights=None, scale="n", size=640, save=None, device="cuda:0", seed=42, log=print,
@@ -56,6 +66,8 @@ def train(epochs, batch, data, weights=None, scale="n", size=640, save=None, dev
     else:
         log(f"trainYolo.train: no readable initial weights, seeded random initialisation (seed {seed})")
         state = init_yolo_train_state(scale, nc, seed)
+    validation_results = val(state, data, scale, size, 16, 0.25, 0.6, device)
+    log(f"Validation results before training: {validation_results}")
     opt, warmup_bias_lr = optimizer.lower(), 0.1
     if opt == "auto":
         opt, lr0, momentum = _auto_optimizer(len(samples), B, int(epochs), nc, lr0, momentum)
@@ -98,7 +110,10 @@ def train(epochs, batch, data, weights=None, scale="n", size=640, save=None, dev
     except OSError as e:
         log(f"trainYolo.train: cannot write {out}: {e}")
         out = None
-    return {"epochs": hist, "weights": out, "not_built": NOT_BUILT, "optimizer": opt, "lr0": lr0, "accumulate": accumulate}
+    final = val(tr.state_dict(ema=True), data, scale, size, 16, 0.25, 0.6, device)
+    log(f"Validation results after training: {final}")
+    return {"epochs": hist, "weights": out, "not_built": NOT_BUILT, "optimizer": opt, "lr0": lr0, "accumulate": accumulate,
+            "val_before": validation_results, "val_after": final}
 
 
 def yoloRetrain():
