@@ -306,9 +306,10 @@ int yv_bn_act_bwd(const void* da, long long ldda, const void* z, long long ldz, 
 int yv_view_op(int mode, const void* src, long long ld_src, void* dst, long long ld_dst, int B, int H, int W, int C,
                void* stream);
 
-/* din += adjoint of max_pool2d(k 5, s 1, p 2) at dout, the maximum of a window being its first one in scan order. */
+/* din += adjoint of max_pool2d(k 5, s 1, p 2) at dout, the maximum of a window being its first one in scan order.
+ * ws: B*H*W*C bytes (per-window argmax offsets). */
 int yv_maxpool5_bwd(const void* x, long long ldx, const void* dout, long long lddo, void* din, long long lddi, int B, int H,
-                    int W, int C, void* stream);
+                    int W, int C, void* ws, size_t ws_bytes, void* stream);
 
 /* col (B*Hout*Wout, 9*C) = 3x3 / pad 1 patches of x (B,Hin,Win,C), K order (ky,kx,c): the X operand of yv_wgrad. */
 int yv_im2col3(const void* x, long long ldx, int B, int Hin, int Win, int C, int stride, void* col, void* stream);

@@ -273,9 +273,46 @@ __global__ __launch_bounds__(256) void view_op_kernel(int mode, const uint16_t* 
     *(uint4*)d = pack8(o);
 }
 
-__global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const uint16_t* __restrict__ x, long long ldx,
-                                                           const uint16_t* __restrict__ dout, long long lddo,
-                                                           uint16_t* __restrict__ din, long long lddi, int B, int H, int W, int C) {
+// Two passes: (1) per window (= output position) the offset 0..24 of its first maximum in scan order, one byte per
+// channel; (2) per input position, the 25 windows that contain it are looked up in that map (the first version
+// recomputed every window's argmax per input position: 625 loads per element, 290 us per call).
+__global__ __launch_bounds__(256) void maxpool5_argmax_kernel(const uint16_t* __restrict__ x, long long ldx, int B, int H, int W,
+                                                              int C, uint8_t* __restrict__ amap /* (B*H*W, C) */) {
+    const int cg = C >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * H * W * cg) return;
+    const int g = (int)(idx % cg);
+    const long long p = idx / cg;
+    const int wx = (int)(p % W);
+    const long long q = p / W;
+    const int wy = (int)(q % H), b = (int)(q / H);
+    const uint16_t* xb = x + (long long)b * H * W * ldx + g * 8;
+    float best[8];
+    int bo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bo[i] = 12; }
+    for (int dy = 0; dy < 5; ++dy) {
+        const int yy = wy + dy - 2;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = 0; dx < 5; ++dx) {
+            const int xx = wx + dx - 2;
+            if (xx < 0 || xx >= W) continue;
+            float v[8];
+            unpack8(*(const uint4*)(xb + ((long long)yy * W + xx) * ldx), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (v[i] > best[i]) { best[i] = v[i]; bo[i] = dy * 5 + dx; }
+        }
+    }
+    uint2 o;
+    o.x = (uint32_t)bo[0] | ((uint32_t)bo[1] << 8) | ((uint32_t)bo[2] << 16) | ((uint32_t)bo[3] << 24);
+    o.y = (uint32_t)bo[4] | ((uint32_t)bo[5] << 8) | ((uint32_t)bo[6] << 16) | ((uint32_t)bo[7] << 24);
+    *(uint2*)(amap + p * C + g * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const uint8_t* __restrict__ amap, const uint16_t* __restrict__ dout,
+                                                           long long lddo, uint16_t* __restrict__ din, long long lddi, int B, int H,
+                                                           int W, int C) {
     const int cg = C >> 3;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)B * H * W * cg) return;
@@ -284,34 +321,22 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const uint16_t* __res
     const int px = (int)(p % W);
     const long long q = p / W;
     const int py = (int)(q % H), b = (int)(q / H);
-    const uint16_t* xb = x + (long long)b * H * W * ldx + g * 8;
     float acc[8];
     unpack8(*(const uint4*)(din + p * lddi + g * 8), acc);
     for (int wy = py - 2; wy <= py + 2; ++wy) {
         if (wy < 0 || wy >= H) continue;
         for (int wx = px - 2; wx <= px + 2; ++wx) {
             if (wx < 0 || wx >= W) continue;
-            // window centred at (wy, wx): first maximum in (row, column) scan order
-            float best[8];
-            int by[8], bx[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; by[i] = -1; bx[i] = -1; }
-            for (int yy = wy - 2; yy <= wy + 2; ++yy) {
-                if (yy < 0 || yy >= H) continue;
-                for (int xx = wx - 2; xx <= wx + 2; ++xx) {
-                    if (xx < 0 || xx >= W) continue;
-                    float v[8];
-                    unpack8(*(const uint4*)(xb + ((long long)yy * W + xx) * ldx), v);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (v[i] > best[i]) { best[i] = v[i]; by[i] = yy; bx[i] = xx; }
-                }
-            }
+            const long long wp = ((long long)b * H + wy) * W + wx;
+            const uint2 m = *(const uint2*)(amap + wp * C + g * 8);
+            const int want = (py - wy + 2) * 5 + (px - wx + 2);              // this position as an offset inside that window
             float d[8];
-            unpack8(*(const uint4*)(dout + (((long long)b * H + wy) * W + wx) * lddo + g * 8), d);
+            unpack8(*(const uint4*)(dout + wp * lddo + g * 8), d);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (by[i] == py && bx[i] == px) acc[i] += d[i];
+            for (int i = 0; i < 8; ++i) {
+                const int off = (int)(((i < 4 ? m.x : m.y) >> (8 * (i & 3))) & 0xff);
+                if (off == want) acc[i] += d[i];
+            }
         }
     }
     *(uint4*)(din + p * lddi + g * 8) = pack8(acc);
@@ -442,11 +467,15 @@ extern "C" int yv_view_op(int mode, const void* src, long long ld_src, void* dst
 }
 
 extern "C" int yv_maxpool5_bwd(const void* x, long long ldx, const void* dout, long long lddo, void* din, long long lddi, int B,
-                               int H, int W, int C, void* stream) {
-    if (!x || !dout || !din || B <= 0 || H <= 0 || W <= 0 || C < 8 || (C & 7)) return YV_ERR_ARG;
-    if ((ldx & 7) || (lddo & 7) || (lddi & 7) || (((uintptr_t)x | (uintptr_t)dout | (uintptr_t)din) & 15)) return YV_ERR_ARG;
-    hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(blocks_for((long long)B * H * W * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)x, ldx, (const uint16_t*)dout, lddo, (uint16_t*)din, lddi, B, H, W, C);
+                               int H, int W, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dout || !din || !ws || B <= 0 || H <= 0 || W <= 0 || C < 8 || (C & 7)) return YV_ERR_ARG;
+    if ((ldx & 7) || (lddo & 7) || (lddi & 7) || (((uintptr_t)x | (uintptr_t)dout | (uintptr_t)din | (uintptr_t)ws) & 15)) return YV_ERR_ARG;
+    if (ws_bytes < (size_t)B * H * W * C) return YV_ERR_WORKSPACE;
+    const unsigned blocks = blocks_for((long long)B * H * W * (C >> 3));
+    hipLaunchKernelGGL(maxpool5_argmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx, B, H, W, C,
+                       (uint8_t*)ws);
+    hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)ws,
+                       (const uint16_t*)dout, lddo, (uint16_t*)din, lddi, B, H, W, C);
     return yv_launch_status();
 }
 

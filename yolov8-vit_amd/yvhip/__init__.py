@@ -67,7 +67,7 @@ _SIGS = {
     "yv_bn_act_bwd": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, C.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp,
                            _vp, C.c_longlong, _vp, _sz, _vp]),
     "yv_view_op": (_i, [_i, _vp, C.c_longlong, _vp, C.c_longlong, _i, _i, _i, _i, _vp]),
-    "yv_maxpool5_bwd": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, _vp, C.c_longlong, _i, _i, _i, _i, _vp]),
+    "yv_maxpool5_bwd": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, _vp, C.c_longlong, _i, _i, _i, _i, _vp, _sz, _vp]),
     "yv_im2col3": (_i, [_vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp]),
     "yv_conv_weight_dgrad": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "yv_conv2d": (_i, [C.POINTER(yv_view), C.POINTER(yv_view), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
@@ -544,8 +544,17 @@ def view_op(mode: int, src: Optional["yv_view"], dst: "yv_view", B: int, H: int,
                          W, Cn if Cn is not None else dst.c, _st()), "yv_view_op")
 
 
+_POOL_WS = {}
+
+
 def maxpool5_bwd(x: "yv_view", dout: "yv_view", din: "yv_view", B: int, H: int, W: int):
-    check(lib.yv_maxpool5_bwd(x.ptr, x.ld, dout.ptr, dout.ld, din.ptr, din.ld, B, H, W, x.c, _st()), "yv_maxpool5_bwd")
+    need = B * H * W * x.c
+    dev = torch.cuda.current_device()
+    ws = _POOL_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _POOL_WS[dev] = torch.empty(need, dtype=torch.uint8, device=f"cuda:{dev}")
+    check(lib.yv_maxpool5_bwd(x.ptr, x.ld, dout.ptr, dout.ld, din.ptr, din.ld, B, H, W, x.c, _p(ws), ws.numel(), _st()),
+          "yv_maxpool5_bwd")
 
 
 def im2col3(x: "yv_view", B: int, Hin: int, Win: int, stride: int, col: torch.Tensor):
