@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(ActArgs a) {
     const int rp = 256 / cg;
     const int lane_r = threadIdx.x / cg, g = threadIdx.x - lane_r * cg;
     if (lane_r >= rp) return;
-    float sc[8], sh[8], k1[8], k2[8], gam[8], bet[8], mu[8], rs[8];
+    float sc[8], k1[8], k2[8], gam[8], bet[8], mu[8], rs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = g * 8 + i;
@@ -220,7 +220,6 @@ __global__ __launch_bounds__(256) void bn_act_kernel(ActArgs a) {
         }
         *(uint4*)(a.out + r * a.ldo + g * 8) = pack8(o);
     }
-    (void)sh;
 }
 
 // ---- view ops --------------------------------------------------------------------------------------------
