@@ -16,7 +16,20 @@ g = torch.Generator().manual_seed(1234)
 images = torch.randint(0, 256, (32, 640, 640, 3), generator=g, dtype=torch.uint8).to(dev)
 runner = PipelinedRunner(pipe)
 r_split = PipelinedRunner(pipe, split_classifier=True)
-opts = [("single stream", pipe), ("two streams", runner.submit), ("two streams + split ViT", r_split.submit)]
+def with_opt(key, val, fn):
+    def run(x):
+        yvhip.set_option(key, val)
+        return fn(x)
+    return run
+
+
+# E2E_OPTION="key:a,b" compares two values of a yv_set_option knob under the two-stream schedule
+spec = os.environ.get("E2E_OPTION")
+if spec:
+    key, vals = spec.split(":")
+    opts = [(f"{key}={v}", with_opt(key, int(v), runner.submit)) for v in vals.split(",")]
+else:
+    opts = [("single stream", pipe), ("two streams", runner.submit), ("two streams + split ViT", r_split.submit)]
 res = {k: [] for k, _ in opts}
 for _ in range(3):
     pipe(images)
@@ -31,4 +44,4 @@ for rd in range(6):
         res[k].append((time.perf_counter() - t0) / 8 * 1e3)
 for k, ts in res.items():
     ts = sorted(ts)
-    print(f"{k:14s} median {ts[len(ts)//2]:.3f} ms  min {ts[0]:.3f} ms  -> {32/ts[len(ts)//2]*1e3:.0f} img/s")
+    print(f"{k:24s} median {ts[len(ts)//2]:.3f} ms  min {ts[0]:.3f} ms  -> {32/ts[len(ts)//2]*1e3:.0f} img/s")
