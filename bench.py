@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--crops", type=int, default=4, help="crops classified per image (cap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no detector/classifier overlap across batches")
+    ap.add_argument("--models", choices=["base", "large"], default="base",
+                    help="base = YOLOv8n + ViT-B/16 (configs[1], the headline); large = YOLOv8m + ViT-L/16 in bf16 "
+                         "(the model pair of configs[4]; its FP8 arithmetic is not built, so this is NOT that config's number)")
     ap.add_argument("--mode", choices=["infer", "train", "train-yolo"], default="infer",
                     help="infer = headline metric (configs[1]); train = ViT-B/16 fine-tune step (configs[2]); "
                          "train-yolo = YOLOv8s training step (configs[3])")
@@ -158,10 +161,12 @@ def main():
     if args.mode == "train-yolo":
         return bench_train_yolo(args, rank, world, dev, dist)
 
-    vit_name = "vit_base_patch16_224"
-    yolo_sd = engines.init_yolo_state("n", 5, seed=42, head_gain=4.0)
+    large = args.models == "large"
+    vit_name = "vit_large_patch16_224" if large else "vit_base_patch16_224"
+    yscale = "m" if large else "n"
+    yolo_sd = engines.init_yolo_state(yscale, 5, seed=42, head_gain=4.0)
     vit_sd = engines.init_vit_wrapper_state(vit_name, 5, seed=42)
-    yolo = engines.YoloEngine(yolo_sd, "n", 5, 640, device=str(dev))
+    yolo = engines.YoloEngine(yolo_sd, yscale, 5, 640, device=str(dev))
     vit = engines.VitEngine(vit_sd, vit_name, 5, device=str(dev))
     B, R = args.batch, args.crops
     pipe = DetectClassifyPipeline(yolo, [vit], max_crops_per_image=R)
@@ -211,8 +216,10 @@ def main():
             "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "YOLOv8n(nc=5)+ViT-B/16 end-to-end inference, 640x640, bf16 "
-                                   "(BASELINE.json configs[1])", "batch_per_gpu": B, "global_batch": B * world,
+            "config": {"workload": ("YOLOv8m(nc=5)+ViT-L/16 end-to-end inference, 640x640, bf16 (model pair of BASELINE.json "
+                                    "configs[4]; FP8 not built)") if large else
+                                   ("YOLOv8n(nc=5)+ViT-B/16 end-to-end inference, 640x640, bf16 "
+                                    "(BASELINE.json configs[1])"), "batch_per_gpu": B, "global_batch": B * world,
                        "crops_per_image": R, "crops_per_step_rank0": crops_step, "parallelism": f"dp{world}",
                        "schedule": "single stream" if runner is None else "2 HIP streams: detector of batch i+1 overlaps classifier of batch i",
                        "weights": "random-init, seed 42"},
@@ -222,7 +229,7 @@ def main():
                          "avg_launch_us": ms * 1e3 / max(n_launch, 1),
                          "alg_flop_per_launch": flops / max(n_launch, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not large:
             line["cpu_baseline"] = cpu_baseline(yolo_sd, vit_sd, vit_name, R)
         print(json.dumps(line), flush=True)
     if dist is not None:

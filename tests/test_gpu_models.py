@@ -106,6 +106,42 @@ def test_pipelined_runner_matches_single_stream():
                 assert torch.equal(o[k], r[k]), (split, k)
 
 
+def test_pipelined_runner_with_dropped_results():
+    """The throughput loop of bench.py: every batch's result dict is dropped as soon as the next batch is submitted,
+    so the caching allocator may recycle the detector->classifier hand-off buffers while an earlier classifier pass is
+    still queued.  Different images per batch; per-batch results are copied (on the classify stream) into buffers
+    allocated up front and must equal the single-stream results."""
+    from yvhip import engines
+    from yvhip.pipeline import DetectClassifyPipeline, PipelinedRunner
+    name, S, B = "vit_tiny_test", 128, 4
+    pipe = DetectClassifyPipeline(engines.YoloEngine(engines.init_yolo_state("n", 5, 3, 4.0), "n", 5, S, DEV),
+                                  [engines.VitEngine(engines.init_vit_wrapper_state(name, 5, 4), name, 5, device=DEV)],
+                                  max_crops_per_image=3)
+    g = torch.Generator().manual_seed(21)
+    batches = [torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).to(DEV) for _ in range(8)]
+    keys = ("crop_list", "crop_total", "cls_logits", "cls_label")
+    ref = []
+    for im in batches:
+        o = pipe(im)
+        torch.cuda.synchronize()
+        ref.append({k: o[k].clone() for k in keys})
+    assert len({tuple(r["crop_list"].flatten().tolist()) for r in ref}) > 1        # the batches really differ
+    keep = [{k: torch.empty_like(v) for k, v in r.items()} for r in ref]
+    torch.cuda.synchronize()
+    runner = PipelinedRunner(pipe)
+    for rnd in range(3):
+        for i, im in enumerate(batches):
+            o = runner.submit(im)
+            with torch.cuda.stream(runner.s_cls):
+                for k in keys:
+                    keep[i][k].copy_(o[k])
+            del o                                                   # like `out = step(images)` in a loop
+        runner.sync()
+        for i, r in enumerate(ref):
+            for k in keys:
+                assert torch.equal(keep[i][k], r[k]), (rnd, i, k)
+
+
 def test_pipeline_with_zero_detections():
     """No candidate above the score threshold: every later stage sees an empty batch (device-side count 0)."""
     from yvhip import engines

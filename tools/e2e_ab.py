@@ -28,6 +28,8 @@ spec = os.environ.get("E2E_OPTION")
 if spec:
     key, vals = spec.split(":")
     opts = [(f"{key}={v}", with_opt(key, int(v), runner.submit)) for v in vals.split(",")]
+elif os.environ.get("E2E_RUN_AHEAD"):
+    opts = [(f"run_ahead={k}", PipelinedRunner(pipe, run_ahead=int(k)).submit) for k in os.environ["E2E_RUN_AHEAD"].split(",")]
 else:
     opts = [("single stream", pipe), ("two streams", runner.submit), ("two streams + split ViT", r_split.submit)]
 res = {k: [] for k, _ in opts}

@@ -34,7 +34,7 @@ template <int LAYOUT>
 __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restrict__ images, int H, int W,
                                                           size_t img_stride, const int32_t* __restrict__ crop_list,
                                                           const int32_t* __restrict__ crop_total, int S, int P,
-                                                          int rows_per_block, float rcp, void* __restrict__ out) {
+                                                          int rows_per_block, float rcp, void* __restrict__ out, int n_images) {
     __shared__ int tx[CR_MAX_S];
     __shared__ int ty_sh[64];
     const int r = blockIdx.y;
@@ -44,6 +44,9 @@ __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restr
     const int cw = x1 - x0, ch = y1 - y0;
     const int row0 = blockIdx.x * rows_per_block;
     if (cw <= 0 || ch <= 0) return;      // degenerate rect: compaction never emits one; guard anyway
+    // a record that does not lie inside an image of the batch is never read from (defence against a corrupted list:
+    // an out-of-range gather would be a GPU memory fault)
+    if (img < 0 || img >= n_images || x0 < 0 || y0 < 0 || x1 > W || y1 > H) return;
     for (int d = threadIdx.x; d < S; d += CR_THREADS) tx[d] = (x0 + nearest_src(d, S, cw)) * 3;
     for (int d = threadIdx.x; d < rows_per_block; d += CR_THREADS) ty_sh[d] = y0 + nearest_src(row0 + d, S, ch);
     __syncthreads();
@@ -138,13 +141,13 @@ extern "C" int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, s
     hipStream_t st = (hipStream_t)stream;
     if (layout == 0)
         hipLaunchKernelGGL(crop_kernel<0>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
-                           out_size, patch, rows, rcp, out);
+                           out_size, patch, rows, rcp, out, B);
     else if (layout == 1)
         hipLaunchKernelGGL(crop_kernel<1>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
-                           out_size, patch, rows, rcp, out);
+                           out_size, patch, rows, rcp, out, B);
     else
         hipLaunchKernelGGL(crop_kernel<2>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
-                           out_size, patch, rows, rcp, out);
+                           out_size, patch, rows, rcp, out, B);
     return yv_launch_status();
 }
 

@@ -123,22 +123,33 @@ class PipelinedRunner:
     valid once `sync()` (or the dict's "done" event) has completed.
 
     Hazards: the detector's activation buffers are private to the detect stream (in order); the classifier's
-    buffers are private to the classify stream; the hand-off (crop list, counts) is a fresh allocation per batch,
-    published by an event.  The classifier's patch buffer is reused every batch on ONE stream, so no extra wait
-    is needed there."""
+    buffers are private to the classify stream; the hand-off (crop list, counts, detections) is a fresh allocation
+    per batch on the detect stream, published by an event and `record_stream`-ed for the classify stream - torch's
+    caching allocator would otherwise hand a dropped batch's blocks to the NEXT detect pass while the classifier of
+    that batch has not read them yet (seen as a memory fault with YOLOv8m + ViT-L at batch 64).  Back-pressure: the
+    detect stream may run at most one batch ahead of the classify stream (it waits for the classifier of batch i-2)."""
 
-    def __init__(self, pipe: DetectClassifyPipeline, split_classifier: bool = False):
+    def __init__(self, pipe: DetectClassifyPipeline, split_classifier: bool = False, run_ahead: int = 1):
         self.pipe = pipe
+        self.run_ahead = max(int(run_ahead), 1)                    # batches the detect stream may lead the classifier by
         self.s_det = torch.cuda.Stream()
         self.s_cls = torch.cuda.Stream()
         self.s_sub = [torch.cuda.Stream(), torch.cuda.Stream()] if split_classifier else None
         self._last = None
+        self._done = []                                            # "classifier finished" events of the last two batches
 
     def submit(self, images: torch.Tensor, ratio=None, dwdh=None, img_wh=None, src_images=None) -> dict:
         cur = torch.cuda.current_stream()
         self.s_det.wait_stream(cur)                               # inputs produced on the caller's stream
+        if len(self._done) > self.run_ahead:
+            self.s_det.wait_event(self._done[-1 - self.run_ahead])  # at most `run_ahead` batches ahead of the classifier
         with torch.cuda.stream(self.s_det):
             det = self.pipe.detect_stage(images, ratio, dwdh, img_wh)
+            for t in det.values():
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(self.s_cls)                     # consumed on the classify stream
+                    for st in (self.s_sub or []):
+                        t.record_stream(st)
             ready = torch.cuda.Event()
             ready.record(self.s_det)
         with torch.cuda.stream(self.s_cls):
@@ -147,6 +158,7 @@ class PipelinedRunner:
             done = torch.cuda.Event()
             done.record(self.s_cls)
         out["done"] = done
+        self._done = (self._done + [done])[-(self.run_ahead + 1):]
         self._last = out
         return out
 
