@@ -264,3 +264,16 @@ def test_detection_metrics_hand_cases():
     assert res2["ap"].shape == (3, 10) and abs(res2["map50"] - 2 * 0.995 / 3) < 1e-9   # class 2 never predicted: AP 0
     empty = ap_per_class(np.zeros((0, 10), bool), np.zeros(0), np.zeros(0), np.array([0, 1]))
     assert empty["map"] == 0.0
+
+
+def test_yolo2dict(tmp_path):
+    """utils.trainYolo.yolo2dict (utils/trainYolo.py:41-122) on xml written by generate_annotation."""
+    import utils.trainYolo as ty
+    from utils.utils import generate_annotation
+    generate_annotation("d", "b.jpg", "b.jpg", [{"sort": "lose", "xmin": 1, "ymin": 2, "xmax": 30, "ymax": 40},
+                                                 {"sort": 3, "xmin": 5, "ymin": 6, "xmax": 7, "ymax": 8}], save_dir=str(tmp_path) + "/")
+    generate_annotation("d", "a.jpg", "a.jpg", [{"sort": "mystery", "xmin": 0, "ymin": 0, "xmax": 1, "ymax": 1}], save_dir=str(tmp_path) + "/")
+    res = ty.yolo2dict(str(tmp_path))
+    assert [r[0] for r in res] == ["a.jpg", "b.jpg"]
+    assert res[0][1] == [{'name': -1, 'xmin': 0, 'ymin': 0, 'xmax': 1, 'ymax': 1}]
+    assert res[1][1] == [{'name': 2, 'xmin': 1, 'ymin': 2, 'xmax': 30, 'ymax': 40}, {'name': 3, 'xmin': 5, 'ymin': 6, 'xmax': 7, 'ymax': 8}]

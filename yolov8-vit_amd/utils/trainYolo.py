@@ -116,6 +116,28 @@ def train(epochs, batch, data, weights=None, scale="n", size=640, save=None, dev
             "val_before": validation_results, "val_after": final}
 
 
+def yolo2dict(path_to_xml_dir):
+    """utils/trainYolo.py:41-122: VOC xml directory -> [(image file name, [{'name': class id, 'xmin', 'ymin', 'xmax',
+    'ymax'}, ...])] sorted by file name; class from <name> (falling back to <sort>), numeric strings '0'..'4' taken as
+    ids, unknown names -> -1; image name = xml stem + '.jpg' ('.png' for the one file the reference special-cases)."""
+    import xml.etree.ElementTree as ET
+    label_mapping = {'good': 0, 'broke': 1, 'lose': 2, 'loss': 2, 'uncovered': 3, 'circle': 4}
+    results = []
+    for xml_file in [f for f in os.listdir(path_to_xml_dir) if f.endswith('.xml')]:
+        base = os.path.splitext(xml_file)[0]
+        objs = []
+        for obj in ET.parse(os.path.join(path_to_xml_dir, xml_file)).getroot().findall('object'):
+            tag = obj.find('name') if obj.find('name') is not None else obj.find('sort')
+            name = tag.text
+            label = int(name) if name in ['0', '1', '2', '3', '4'] else label_mapping.get(name, -1)
+            bb = obj.find('bndbox')
+            objs.append({'name': label, 'xmin': int(bb.find('xmin').text), 'ymin': int(bb.find('ymin').text),
+                         'xmax': int(bb.find('xmax').text), 'ymax': int(bb.find('ymax').text)})
+        results.append((base + ('.png' if base == "test152" else '.jpg'), objs))
+    results.sort(key=lambda x: x[0])
+    return results
+
+
 def yoloRetrain():
     """utils/trainYolo.py:124-137 (app.py:99-100 runs this on a background thread and ignores the result):
     VOC xml -> YOLO txt, then one epoch at batch 1."""
