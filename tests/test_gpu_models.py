@@ -142,6 +142,39 @@ def test_pipelined_runner_with_dropped_results():
                 assert torch.equal(keep[i][k], r[k]), (rnd, i, k)
 
 
+def test_step_is_graph_capturable():
+    """The whole detect -> NMS -> crop -> classify step has no host synchronisation (the crop count stays on the
+    device), so it can be captured into one hipGraph and replayed on new images: results equal the eager step."""
+    from yvhip import engines
+    from yvhip.pipeline import DetectClassifyPipeline
+    name, S, B = "vit_tiny_test", 128, 4
+    pipe = DetectClassifyPipeline(engines.YoloEngine(engines.init_yolo_state("n", 5, 3, 4.0), "n", 5, S, DEV),
+                                  [engines.VitEngine(engines.init_vit_wrapper_state(name, 5, 4), name, 5, device=DEV)],
+                                  max_crops_per_image=3)
+    g = torch.Generator().manual_seed(31)
+    batches = [torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).to(DEV) for _ in range(4)]
+    keys = ("det_count", "det_box", "crop_list", "crop_total", "cls_logits", "cls_label")
+    ref = []
+    for im in batches:
+        o = pipe(im)
+        torch.cuda.synchronize()
+        ref.append({k: o[k].clone() for k in keys})
+    static = batches[0].clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                                  # warm the capture stream's workspace registration
+        pipe(static)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = pipe(static)
+    for im, r in zip(batches, ref):
+        static.copy_(im)
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(out[k], r[k]), k
+
+
 def test_pipeline_with_zero_detections():
     """No candidate above the score threshold: every later stage sees an empty batch (device-side count 0)."""
     from yvhip import engines

@@ -28,6 +28,19 @@ spec = os.environ.get("E2E_OPTION")
 if spec:
     key, vals = spec.split(":")
     opts = [(f"{key}={v}", with_opt(key, int(v), runner.submit)) for v in vals.split(",")]
+elif os.environ.get("E2E_GRAPH"):
+    static = images.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        pipe(static)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gout = pipe(static)
+    r_hi = PipelinedRunner(pipe, det_priority=-1)
+    r_new = PipelinedRunner(pipe)
+    opts = [("single stream eager", pipe), ("single stream hipGraph", lambda x: graph.replay()), ("two streams", runner.submit),
+            ("two streams det-high-prio", r_hi.submit), ("two streams (new runner)", r_new.submit)]
 elif os.environ.get("E2E_RUN_AHEAD"):
     opts = [(f"run_ahead={k}", PipelinedRunner(pipe, run_ahead=int(k)).submit) for k in os.environ["E2E_RUN_AHEAD"].split(",")]
 else:

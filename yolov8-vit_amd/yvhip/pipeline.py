@@ -127,12 +127,16 @@ class PipelinedRunner:
     per batch on the detect stream, published by an event and `record_stream`-ed for the classify stream - torch's
     caching allocator would otherwise hand a dropped batch's blocks to the NEXT detect pass while the classifier of
     that batch has not read them yet (seen as a memory fault with YOLOv8m + ViT-L at batch 64).  Back-pressure: the
-    detect stream may run at most one batch ahead of the classify stream (it waits for the classifier of batch i-2)."""
+    detect stream may run at most one batch ahead of the classify stream (it waits for the classifier of batch i-2).
+    The detect stream is created with HIGH priority: HIP maps equal-priority streams round-robin onto a few hardware
+    queues, and two streams that land on the same queue do not overlap at all (measured in one process: 9.58 ms for an
+    unlucky pair vs 8.61 ms with the priority split; a lucky pair gives the same 8.6-8.9 ms)."""
 
-    def __init__(self, pipe: DetectClassifyPipeline, split_classifier: bool = False, run_ahead: int = 1):
+    def __init__(self, pipe: DetectClassifyPipeline, split_classifier: bool = False, run_ahead: int = 1,
+                 det_priority: int = -1):
         self.pipe = pipe
         self.run_ahead = max(int(run_ahead), 1)                    # batches the detect stream may lead the classifier by
-        self.s_det = torch.cuda.Stream()
+        self.s_det = torch.cuda.Stream(priority=det_priority)
         self.s_cls = torch.cuda.Stream()
         self.s_sub = [torch.cuda.Stream(), torch.cuda.Stream()] if split_classifier else None
         self._last = None
