@@ -43,6 +43,11 @@ def cpu_baseline(yolo_sd, vit_sd, vit_name, crops, budget_s=20.0, max_images=8):
             "sample": f"{n} synthetic 640x640 images, batch-1 fp32 loop, {crops} crops/image, {dt:.1f}s"}
 
 
+# HIP maps streams round-robin onto GPU_MAX_HW_QUEUES hardware queues (default 4); the schedule below uses 4 streams next to
+# the default one, and two streams that share a queue do not overlap.  Must be set before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def bench_train(args, rank, world, dev, dist):
     """BASELINE.json configs[2]: ViT-B/16 fine-tune fwd+bwd+SGD, 224x224, 32 crops per GPU (256 at DP=8), bf16 compute,
     fp32 master weights, gradient all-reduce over RCCL overlapped with backward."""
@@ -134,6 +139,7 @@ def main():
     ap.add_argument("--crops", type=int, default=4, help="crops classified per image (cap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no detector/classifier overlap across batches")
+    ap.add_argument("--no-split", action="store_true", help="keep the classifier of a batch on one stream (no half-batch overlap)")
     ap.add_argument("--models", choices=["base", "large"], default="base",
                     help="base = YOLOv8n + ViT-B/16 (configs[1], the headline); large = YOLOv8m + ViT-L/16 in bf16 "
                          "(the model pair of configs[4]; its FP8 arithmetic is not built, so this is NOT that config's number)")
@@ -177,7 +183,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    runner = None if args.no_overlap else PipelinedRunner(pipe)
+    runner = None if args.no_overlap else PipelinedRunner(pipe, split_classifier=not args.no_split)
     step = pipe if runner is None else runner.submit
     for _ in range(max(args.warmup, 1)):
         out = step(images)
@@ -185,12 +191,22 @@ def main():
     crops_step = int(out["crop_total"][0])
 
     # HIP events around every launch of the dominant kernel (the 128x128 MFMA GEMM instance)
+    # HIP events of the dominant kernel are attached to its launches (hipExtLaunchKernel: timestamps of the kernel's own
+    # dispatch packet).  A hipEventRecord pair around every launch would be two barrier packets per launch: ~1.5 ms per
+    # step and it serialises the concurrent half-batches (measured: 9.77 ms vs 8.22 ms clean).  As a further precaution
+    # the timed region carries the events on a sample of its steps only (2 of them for K >= 6).
     recs = []
-    yvhip.LINEAR_HOOK = lambda M, N, K, e0, e1: recs.append((2.0 * M * N * K, e0, e1))
+    hook = lambda M, N, K, e0, e1: recs.append((2.0 * M * N * K, e0, e1))
+    sampled = {args.steps // 3, (2 * args.steps) // 3} if args.steps >= 6 else {args.steps - 1}
+    if os.environ.get("BENCH_NO_HOOK"):
+        sampled = set()
     barrier()
     torch.cuda.synchronize()
+    base_ev = yvhip.HipEvent()
+    base_ev.record()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        yvhip.LINEAR_HOOK = hook if i in sampled else None
         out = step(images)
     torch.cuda.synchronize()
     barrier()
@@ -203,7 +219,21 @@ def main():
         flops = sum(f for f, _, _ in recs)
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs)
         n_launch = len(recs)
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # The classifier runs as two concurrent half-batches, so launches of the kernel overlap in time and each one's
+        # event-to-event duration covers a period in which it owns only part of the chip.  Rate of the kernel = its
+        # algorithmic flops / the time during which at least one launch of it is executing (union of the intervals).
+        iv = sorted((base_ev.elapsed_time(e0), base_ev.elapsed_time(e1)) for _, e0, e1 in recs)
+        busy, cur_s, cur_e = 0.0, None, None
+        for a, b in iv:
+            if cur_e is None or a > cur_e:
+                if cur_e is not None:
+                    busy += cur_e - cur_s
+                cur_s, cur_e = a, b
+            else:
+                cur_e = max(cur_e, b)
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        achieved = flops / (busy * 1e-3) / 1e12 if busy > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -221,12 +251,15 @@ def main():
                                    ("YOLOv8n(nc=5)+ViT-B/16 end-to-end inference, 640x640, bf16 "
                                     "(BASELINE.json configs[1])"), "batch_per_gpu": B, "global_batch": B * world,
                        "crops_per_image": R, "crops_per_step_rank0": crops_step, "parallelism": f"dp{world}",
-                       "schedule": "single stream" if runner is None else "2 HIP streams: detector of batch i+1 overlaps classifier of batch i",
+                       "schedule": "single stream" if runner is None else
+                                   ("HIP streams: detector of batch i+1 (high priority) overlaps classifier of batch i" +
+                                    ("" if args.no_split else "; classifier runs as two concurrent half-batches")),
                        "weights": "random-init, seed 42"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "gemm_dma_kernel<128,128> (all ViT linears)", "launches": n_launch,
-                         "avg_launch_us": ms * 1e3 / max(n_launch, 1),
+                         "avg_launch_us": ms * 1e3 / max(n_launch, 1), "kernel_busy_ms_per_step": busy / max(len(sampled), 1), "instrumented_steps": len(sampled),
+                         "concurrent_launches": runner is not None and not args.no_split,
                          "alg_flop_per_launch": flops / max(n_launch, 1)},
         }
         if world == 1 and not args.no_cpu_baseline and not large:

@@ -41,6 +41,11 @@ int yv_device_is_gfx950(void);
 /* Tuning knobs (process-wide, not part of the reference surface): "linear_variant" (0 register-staged
  * 128x128, 1 LDS-DMA 128x128, 2 256x128, 3 256x256, 4 128x256), "linear_group_m" (M tiles per L2 group). */
 int yv_set_option(const char* key, int value);
+
+/* Measurement hook (bench.py): the NEXT LDS-DMA GEMM launch issued by the calling thread (yv_linear / yv_linear_ex /
+ * yv_linear_nn) records its start / stop timestamps into these hipEvent_t handles through hipExtLaunchKernel, i.e. from
+ * the kernel's own dispatch packet.  Either may be null; the setting is consumed by that launch. */
+int yv_set_launch_timing(void* start_event, void* stop_event);
 /* Registers (ws != NULL) or removes a caller-owned f32 scratch buffer for split-K partial sums used by launches
  * on `stream`.  One buffer per stream: launches of a stream are ordered, different streams must not share one. */
 int yv_set_workspace(void* stream, void* ws, size_t bytes);

@@ -22,11 +22,13 @@
 #include <map>
 #include <mutex>
 #include "yv_common.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
 constexpr int BK = 64;            // bf16 elements per K step
 int g_opt_wgrad_cap = 128;          // token slices of a conv-shaped weight gradient (few output tiles, 10^5+ rows)
+thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;   // yv_set_launch_timing: next gemm_dma launch
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
 int g_opt_group_m = 8;
 int g_opt_staged = 1;
@@ -956,7 +958,15 @@ int launch_dma(GemmArgs& g, hipStream_t st) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;
     const int S = g.splitk > 1 ? g.splitk : 1;
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * S), dim3(WM * WN * 64), lds, st, g);
+    if (t_time_start || t_time_stop) {
+        // timestamps taken from the kernel's own dispatch packet (no extra barrier packets in the queue, unlike a pair of
+        // hipEventRecord calls around the launch)
+        hipExtLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * S), dim3(WM * WN * 64), (uint32_t)lds, st, t_time_start,
+                              t_time_stop, 0, g);
+        t_time_start = t_time_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n * S), dim3(WM * WN * 64), lds, st, g);
+    }
     if (S > 1) {
         const long long items = (long long)g.M * (g.N >> 2);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, g);
@@ -1008,6 +1018,12 @@ extern "C" int yv_set_workspace(void* stream, void* ws, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     if (!ws || !bytes) g_ws.erase(stream);
     else g_ws[stream] = std::make_pair(ws, bytes);
+    return YV_OK;
+}
+
+extern "C" int yv_set_launch_timing(void* start_event, void* stop_event) {
+    t_time_start = (hipEvent_t)start_event;
+    t_time_stop = (hipEvent_t)stop_event;
     return YV_OK;
 }
 

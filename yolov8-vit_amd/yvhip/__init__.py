@@ -9,6 +9,10 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+
+# multi-stream schedules (yvhip.pipeline.PipelinedRunner) need more hardware queues than HIP's default 4; only effective
+# when set before the process's first HIP call, harmless otherwise
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import re
 from typing import List, Optional
 
@@ -45,6 +49,7 @@ _SIGS = {
     "yv_device_is_gfx950": (_i, []),
     "yv_set_option": (_i, [C.c_char_p, _i]),
     "yv_set_workspace": (_i, [_vp, _vp, _sz]),
+    "yv_set_launch_timing": (_i, [_vp, _vp]),
     "yv_custom_nms_ws_bytes": (_sz, [_i, _i]),
     "yv_custom_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "yv_efficient_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -321,6 +326,49 @@ EPI_BIAS, EPI_SILU, EPI_GELU, EPI_RES_F32, EPI_RES_BF16, EPI_OUT_F32, EPI_POSEMB
 LINEAR_HOOK = None      # callable(M, N, K, start_event, end_event) or None
 
 
+_HIP = None
+
+
+def _hip():
+    global _HIP
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        _HIP.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        _HIP.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        _HIP.hipEventDestroy.argtypes = [C.c_void_p]
+        _HIP.hipEventSynchronize.argtypes = [C.c_void_p]
+    return _HIP
+
+
+class HipEvent:
+    """Plain hipEvent_t (timing enabled) for launch-attached timestamps; elapsed_time() in ms like torch.cuda.Event."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+        if _hip().hipEventCreate(C.byref(self.handle)) != 0:
+            raise YvError("hipEventCreate failed")
+
+    def record(self, stream: Optional[int] = None):
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        if _hip().hipEventRecord(self.handle, C.c_void_p(st)) != 0:
+            raise YvError("hipEventRecord failed")
+
+    def elapsed_time(self, other: "HipEvent") -> float:
+        ms = C.c_float()
+        rc = _hip().hipEventElapsedTime(C.byref(ms), self.handle, other.handle)
+        if rc != 0:
+            raise YvError(f"hipEventElapsedTime failed ({rc})")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _hip().hipEventDestroy(self.handle)
+        except Exception:
+            pass
+
+
 def view(t: torch.Tensor, c_off: int, c: int, up: int = 0) -> "yv_view":
     """NHWC bf16 tensor (B,H,W,ld) -> operand view of channels [c_off, c_off+c)."""
     assert t.dtype == torch.bfloat16 and t.is_cuda and t.is_contiguous()
@@ -339,13 +387,13 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
     if bias is not None:
         flags |= EPI_BIAS
     hook = LINEAR_HOOK
-    if hook is not None:                     # bench.py: HIP events around the launch, on the launch stream
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    if hook is not None:                     # bench.py: HIP events attached to the launch itself (hipExtLaunchKernel)
+        e0, e1 = HipEvent(), HipEvent()
+        check(lib.yv_set_launch_timing(e0.handle, e1.handle), "yv_set_launch_timing")
     check(lib.yv_linear(_p(a), a.stride(0), _p(w), _p(bias), Mr, N, K, _p(out), out.stride(0), _p(pos), tok, flags,
                         _p(m_dev), m_mul, _st()), "yv_linear")
     if hook is not None:
-        e1.record()
+        lib.yv_set_launch_timing(None, None)             # not consumed when the call took a non-DMA kernel path
         hook(Mr, N, K, e0, e1)
     return out
 
