@@ -94,12 +94,14 @@ class _Block:
 class YoloTrainer:
     def __init__(self, state: Dict[str, torch.Tensor], scale: str = "n", nc: int = 5, size: int = 640, batch: int = 16,
                  lr: float = 1e-4, momentum: float = 0.937, weight_decay: float = 5e-4, device: str = "cuda:0",
-                 optimizer: str = "sgd", ema: bool = False, ema_decay: float = 0.9999, ema_tau: float = 2000.0):
+                 optimizer: str = "sgd", ema: bool = False, ema_decay: float = 0.9999, ema_tau: float = 2000.0,
+                 overlap_wgrad: bool = True):
         require_gpu()
         if size % 32:
             raise YvError("input size must be a multiple of 32")
         self.scale, self.nc, self.size, self.B, self.dev = scale, nc, size, batch, torch.device(device)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.overlap_wgrad, self.s_w, self._pending = overlap_wgrad, None, []
         if optimizer not in ("sgd", "sgd_nesterov", "adamw"):
             raise YvError("optimizer must be 'sgd', 'sgd_nesterov' or 'adamw'")
         self.optimizer, self.use_ema, self.ema_decay, self.ema_tau = optimizer, ema, ema_decay, ema_tau
@@ -369,15 +371,10 @@ class YoloTrainer:
                        self.gr(b.gamma), self.gr(b.beta), mview(dz), self.ws)
         else:                                                   # da is the f32 loss gradient (T, cout): cast + bias gradient
             cast_colsum(da, dz, self.gr(b.bias), self.ws)
-        dw = self.gr(b.w).view(b.cout, b.taps * b.cin)
-        if b.k == 1:
-            wgrad(dz, x_buf[:, x_off:x_off + b.cin], dw, T=Tp)
+        if self.overlap_wgrad:
+            self._pending.append((b, x_buf, x_off))             # weight gradients run on the side stream (_flush_wgrads)
         else:
-            col = self.col[:Tp * 9 * b.cin].view(Tp, 9 * b.cin)
-            if Tp != T:
-                col[T:].zero_()
-            im2col3(mview(x_buf, x_off, b.cin), self.B, hin, hin, b.s, col)
-            wgrad(dz, col, dw, T=Tp)
+            self._wgrad_block(b, x_buf, x_off)
         if dx is not None:
             wd = self.wd_buf[:b.cin * b.taps * b.cout]
             conv_weight_dgrad(self.w16(b), b.cout, b.taps, b.cin, wd)
@@ -388,6 +385,38 @@ class YoloTrainer:
                 view_op(VIEW_ZERO_INSERT, mview(dz), mview(zi), self.B, hout, hout)
                 src = mview(zi)
             conv_view(src, self.B, hin, hin, b.k, 1, wd.view(b.cin, b.taps * b.cout), b.cin, dx, res=dx)
+
+    def _wgrad_block(self, b: _Block, x_buf: torch.Tensor, x_off: int):
+        hin, hout = self.geom[b.key]
+        T = self.B * hout * hout
+        Tp = _r64(T)
+        dz = self.dz[b.key]
+        dw = self.gr(b.w).view(b.cout, b.taps * b.cin)
+        if b.k == 1:
+            wgrad(dz, x_buf[:, x_off:x_off + b.cin], dw, T=Tp)
+        else:
+            col = self.col[:Tp * 9 * b.cin].view(Tp, 9 * b.cin)
+            if Tp != T:
+                col[T:].zero_()
+            im2col3(mview(x_buf, x_off, b.cin), self.B, hin, hin, b.s, col)
+            wgrad(dz, col, dw, T=Tp)
+
+    def _flush_wgrads(self):
+        """The weight gradients of the blocks back-propagated since the last flush go to a second HIP stream: nothing on
+        the data-gradient chain depends on them (only the optimiser does), and the chain's kernels leave CUs idle.  Hazards:
+        dz of a block is written once per step (main stream, before the event) and activations are read-only in backward;
+        the im2col scratch is private to the side stream; gradient slices are disjoint."""
+        if not self._pending:
+            return
+        if self.s_w is None:
+            self.s_w = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.s_w):
+            self.s_w.wait_event(ev)
+            for b, x_buf, x_off in self._pending:
+                self._wgrad_block(b, x_buf, x_off)
+        self._pending = []
 
     # ------------------------------------------------------------------ forward
     def forward(self, images: torch.Tensor):
@@ -457,6 +486,7 @@ class YoloTrainer:
             self._bwd(d["c2"], dcls, act["c1"].buf, 0, act["c1"].g())
             self._bwd(d["c1"], act["c1"].g(), act["c0"].buf, 0, act["c0"].g())
             self._bwd(d["c0"], act["c0"].g(), f.buf, 0, f.g())
+            self._flush_wgrads()
         for idx, kind, p in reversed(self.layers):
             m = self.mod[idx]
             if m["kind"] == "conv":
@@ -490,6 +520,9 @@ class YoloTrainer:
                 for q in (2, 1, 0):                       # p_{q+1} = maxpool(p_q)
                     maxpool5_bwd(y.v(q * c_, c_), y.g((q + 1) * c_, c_), y.g(q * c_, c_), B, y.H, y.W)
                 self._bwd(m["cv1"], y.g(0, c_), o[idx - 1].buf, 0, o[idx - 1].g())
+            self._flush_wgrads()
+        if self.s_w is not None:
+            torch.cuda.current_stream().wait_stream(self.s_w)      # every weight gradient is in G before the caller goes on
 
     # ------------------------------------------------------------------ loss / step
     def loss(self, gt_boxes: torch.Tensor, gt_labels: torch.Tensor, gt_counts: torch.Tensor, gains=(7.5, 0.5, 1.5)):
