@@ -72,6 +72,7 @@ class VitTrainer:
         self.P16.copy_(self.P)                               # initial cast (plumbing); afterwards the SGD kernel mirrors
         self.refresh_working_copies()
         self._bufs: Dict[int, dict] = {}
+        self.s_w = None                                      # side stream of the weight gradients (backward)
         from .dist import BucketReducer
         self.reducer = BucketReducer(self.G, int(bucket_mb * 1024 * 1024 / 4))
 
@@ -134,6 +135,10 @@ class VitTrainer:
                  delta=f32(R * self.H * N), dfeats=full["dfeats"][:R], dc=b16(R, D),
                  dtok=full["dtok"][:R * self.tok], dtok32=f32(R * self.tok, D), patches=full["patches"][:R * self.tok],
                  dpos=f32(N, D),
+                 # gradient operands of a block's four weight gradients, double-buffered by block parity: the weight
+                 # gradients of block i run on a second stream while the main stream already writes block i-1's set
+                 dy=[dict(dxb_fc2=pad(M, Mp, D), dxb_proj=pad(M, Mp, D), dwide=pad(M, Mp, 4 * D), dqkv=pad(M, Mp, 3 * D),
+                          done=None) for _ in range(2)],
                  ws=f32(max(int(lib.yv_colsum_ws_floats(M, 4 * D)), int(lib.yv_layernorm_bwd_ws_floats(M, D)), 2 * R * 128) + 64))
         self._bufs[R] = b
         return b
@@ -200,30 +205,47 @@ class VitTrainer:
                       self.g("model.norm.weight"), self.g("model.norm.bias"), b["ws"])
         self._launch_ready_buckets(self.off["model.norm.weight"])
         # ---- transformer blocks, last to first -------------------------------------------------------------
+        main = torch.cuda.current_stream()
+        if self.s_w is None:
+            self.s_w = torch.cuda.Stream()
         for i in reversed(range(L)):
             k = f"model.blocks.{i}."
             xin, xmid = b["x"][2 * i], b["x"][2 * i + 1]
-            dx, dxb = b["dx"], b["dxb"]
+            dx = b["dx"]
+            S = b["dy"][i & 1]
+            if S["done"] is not None:
+                main.wait_event(S["done"])                     # block i+2's weight gradients have read this set
+            dxb_fc2, dxb_proj, dwide, dqkv = S["dxb_fc2"][:M], S["dxb_proj"][:M], S["dwide"][:M], S["dqkv"][:M]
             # MLP branch
-            cast_colsum(dx, dxb, self.g(k + "mlp.fc2.bias"), b["ws"])
-            self._wgrad(k + "mlp.fc2.weight", b["full"]["dxb"], b["full"]["g"][i])
-            linear_nn(dxb, Wm(k + "mlp.fc2.weight"), b["dwide"], flags=EPI_GELU_BWD, aux=b["u"][i])
-            colsum_bf16(b["dwide"], self.g(k + "mlp.fc1.bias"), b["ws"])
-            self._wgrad(k + "mlp.fc1.weight", b["full"]["dwide"], b["full"]["h2"][i])
-            linear_nn(b["dwide"], Wm(k + "mlp.fc1.weight"), b["dnar"])
+            cast_colsum(dx, dxb_fc2, self.g(k + "mlp.fc2.bias"), b["ws"])
+            linear_nn(dxb_fc2, Wm(k + "mlp.fc2.weight"), dwide, flags=EPI_GELU_BWD, aux=b["u"][i])
+            colsum_bf16(dwide, self.g(k + "mlp.fc1.bias"), b["ws"])
+            linear_nn(dwide, Wm(k + "mlp.fc1.weight"), b["dnar"])
             layernorm_bwd(xmid, D, self.p(k + "norm2.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm2.weight"), self.g(k + "norm2.bias"), b["ws"])
             # attention branch
-            cast_colsum(dx, dxb, self.g(k + "attn.proj.bias"), b["ws"])
-            self._wgrad(k + "attn.proj.weight", b["full"]["dxb"], b["full"]["o"][i])
-            linear_nn(dxb, Wm(k + "attn.proj.weight"), b["dnar"])
-            attention_bwd(b["qkv"][i], b["o"][i], b["dnar"], b["lse"][i], R, N, H, b["dqkv"], b["delta"])
-            colsum_bf16(b["dqkv"], self.g(k + "attn.qkv.bias"), b["ws"])
-            self._wgrad(k + "attn.qkv.weight", b["full"]["dqkv"], b["full"]["h1"][i])
-            linear_nn(b["dqkv"], Wm(k + "attn.qkv.weight"), b["dnar"])
+            cast_colsum(dx, dxb_proj, self.g(k + "attn.proj.bias"), b["ws"])
+            linear_nn(dxb_proj, Wm(k + "attn.proj.weight"), b["dnar"])
+            attention_bwd(b["qkv"][i], b["o"][i], b["dnar"], b["lse"][i], R, N, H, dqkv, b["delta"])
+            colsum_bf16(dqkv, self.g(k + "attn.qkv.bias"), b["ws"])
+            linear_nn(dqkv, Wm(k + "attn.qkv.weight"), b["dnar"])
             layernorm_bwd(xin, D, self.p(k + "norm1.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm1.weight"), self.g(k + "norm1.bias"), b["ws"])
-            self._launch_ready_buckets(self.off[k + "norm1.weight"])
+            # the block's four weight gradients: nothing on the data-gradient chain needs them, so they run on the side
+            # stream (own split-K workspace) under the next block's chain; the gradient buckets that become final with
+            # them are launched from that stream, i.e. after them
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(self.s_w):
+                self.s_w.wait_event(ev)
+                self._wgrad(k + "mlp.fc2.weight", S["dxb_fc2"], b["full"]["g"][i])
+                self._wgrad(k + "mlp.fc1.weight", S["dwide"], b["full"]["h2"][i])
+                self._wgrad(k + "attn.proj.weight", S["dxb_proj"], b["full"]["o"][i])
+                self._wgrad(k + "attn.qkv.weight", S["dqkv"], b["full"]["h1"][i])
+                self._launch_ready_buckets(self.off[k + "norm1.weight"])
+                S["done"] = torch.cuda.Event()
+                S["done"].record(self.s_w)
+        main.wait_stream(self.s_w)
         # ---- embeddings -----------------------------------------------------------------------------------
         token_reduce(b["dx"], R, N, D, b["dpos"])
         self.g("model.pos_embed").copy_(b["dpos"].view(1, N, D))
