@@ -27,7 +27,8 @@ def with_opt(key, val, fn):
 spec = os.environ.get("E2E_OPTION")
 if spec:
     key, vals = spec.split(":")
-    opts = [(f"{key}={v}", with_opt(key, int(v), runner.submit)) for v in vals.split(",")]
+    r_s = PipelinedRunner(pipe, split_classifier=True)          # the shipped schedule
+    opts = [(f"{key}={v}", with_opt(key, int(v), r_s.submit)) for v in vals.split(",")]
 elif os.environ.get("E2E_SPLIT"):
     opts = [("two streams", runner.submit)] + [(f"split x{k}", PipelinedRunner(pipe, split_classifier=int(k)).submit)
                                                for k in os.environ["E2E_SPLIT"].split(",")]
