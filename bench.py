@@ -71,7 +71,7 @@ def bench_train(args, rank, world, dev, dist):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, dev)
+    dt = max_over_ranks(time.perf_counter() - t0, None if os.environ.get("YV_BENCH_REHEARSAL") == "1" else dev)
     if rank == 0:
         flop = 3.0 * 35.13e9 * R                       # fwd + bwd ~ 3 x forward
         print(json.dumps({"metric": "ViT-B/16 fine-tune images/sec (fwd+bwd+SGD)", "value": world * R * args.steps / dt,
@@ -114,7 +114,7 @@ def bench_train_yolo(args, rank, world, dev, dist):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, dev)
+    dt = max_over_ranks(time.perf_counter() - t0, None if os.environ.get("YV_BENCH_REHEARSAL") == "1" else dev)
     if rank == 0:
         flop = 3.0 * 28.60e9 * B                       # fwd + bwd ~ 3 x forward
         print(json.dumps({"metric": "YOLOv8s training images/sec (fwd+loss+bwd+SGD)", "value": world * B * args.steps / dt,
@@ -151,12 +151,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank control flow on a ONE-GPU box: YV_BENCH_REHEARSAL=1 maps every rank to cuda:0 and uses
+    # gloo (RCCL refuses two ranks on one device); never used by the driver
+    rehearsal = os.environ.get("YV_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import yvhip
     from yvhip import engines
@@ -213,7 +221,7 @@ def main():
     dt = time.perf_counter() - t0
     yvhip.LINEAR_HOOK = None
     from yvhip.dist import max_over_ranks
-    dt = max_over_ranks(dt, dev)
+    dt = max_over_ranks(dt, None if os.environ.get("YV_BENCH_REHEARSAL") == "1" else dev)
 
     if rank == 0:
         flops = sum(f for f, _, _ in recs)
