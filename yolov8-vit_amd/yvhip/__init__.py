@@ -12,11 +12,15 @@ import os
 
 # multi-stream schedules (yvhip.pipeline.PipelinedRunner) need more hardware queues than HIP's default 4; only effective
 # when set before the process's first HIP call, harmless otherwise
+_HWQ_PRESET = os.environ.get("GPU_MAX_HW_QUEUES")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import re
 from typing import List, Optional
 
 import torch
+
+# hardware queues this process will really have: the variable only counts if HIP was not initialised yet
+HW_QUEUES = int(_HWQ_PRESET) if _HWQ_PRESET else (4 if torch.cuda.is_initialized() else 8)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyvhip.so")

@@ -144,6 +144,9 @@ class PipelinedRunner:
         self.s_det = torch.cuda.Stream(priority=det_priority)
         self.s_cls = torch.cuda.Stream()
         n_split = 2 if split_classifier is True else int(split_classifier or 0)      # True = 2 parts, or the number of parts
+        from . import HW_QUEUES
+        if n_split >= 2 and HW_QUEUES < 8:
+            n_split = 0          # with HIP's default 4 hardware queues the extra streams collide and the split is slower
         self.s_sub = [torch.cuda.Stream() for _ in range(n_split)] if n_split >= 2 else None
         self._last = None
         self._done = []                                            # "classifier finished" events of the last two batches
