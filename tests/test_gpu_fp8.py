@@ -1,0 +1,115 @@
+"""MXFP8 linears (BASELINE.json configs[4]: FP8 classifier GEMMs) against a torch emulation on the CPU: the quantiser
+must reproduce the emulated bytes and scales exactly; the block-scaled MFMA GEMM must equal the fp64 product of the
+DEQUANTISED operands up to fp32 accumulation (products of two e4m3 values are exact in fp32)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def yv():
+    import yvhip
+    yvhip.require_gpu()
+    return yvhip
+
+
+def test_mx_mfma_layout(yv):
+    """Executable statement of the v_mfma_scale_f32_16x16x128_f8f6f4 operand layout the GEMM relies on (measured, the
+    image carries no ISA document): lane (row r, group g) holds K 16g..16g+15 and 64+16g..64+16g+15; the scale of the
+    32-block j of row r is byte `opsel` of the scale register of lane (r, group j)."""
+    ONE = 0x38
+    def run(a, b, sa, sb, opsel=0):
+        d = torch.zeros(64, 4, device=DEV)
+        yv.check(yv.lib.yv_mx_probe(a.data_ptr(), b.data_ptr(), sa.data_ptr(), sb.data_ptr(), opsel, d.data_ptr(), None), "probe")
+        torch.cuda.synchronize()
+        return d.cpu()
+    ones = lambda: torch.full((64, 32), ONE, dtype=torch.uint8, device=DEV)
+    zeros = lambda: torch.zeros((64, 32), dtype=torch.uint8, device=DEV)
+    s127 = lambda: torch.full((64,), 127, dtype=torch.int32, device=DEV)
+    assert run(ones(), ones(), s127(), s127()).unique().tolist() == [128.0]
+    row = 5
+    for g in range(4):
+        for half in range(2):
+            a = zeros(); a[g * 16 + row, half * 16:(half + 1) * 16] = ONE          # 16 K elements of row 5
+            block = (16 * g + 64 * half) // 32                                     # the MX block they belong to
+            for j in range(4):
+                sa = s127(); sa[j * 16 + row] = 128                                 # double the scale of block j
+                d = run(a, ones(), sa, s127())
+                exp = 32.0 if j == block else 16.0
+                assert d[(row >> 2) * 16:(row >> 2) * 16 + 16, row & 3].unique().tolist() == [exp], (g, half, j)
+    import numpy as np
+    packed = torch.from_numpy(np.full((64,), 127 | (128 << 8) | (129 << 16) | (130 << 24), dtype=np.uint32).view(np.int32)).to(DEV)
+    unit = torch.from_numpy(np.full((64,), 0x7f7f7f7f, dtype=np.uint32).view(np.int32)).to(DEV)     # 2^0 in every byte
+    for op in range(4):                                      # the probe uses the same opsel for both scale operands
+        assert run(ones(), ones(), packed, unit, op).unique().tolist() == [128.0 * 2 ** op]
+
+
+def emulate_quant(x: torch.Tensor):
+    """x (rows, K) bf16-representable f32 -> (bytes (rows, K) uint8, scale bytes (rows, K/32) uint8, dequantised f64)."""
+    rows, K = x.shape
+    b = x.view(rows, K // 32, 32).double()
+    amax = b.abs().amax(-1)
+    r = (amax / 448.0)
+    e = torch.where(amax > 0, torch.ceil(torch.log2(r.clamp_min(1e-300))), torch.full_like(amax, -127.0))
+    # log2 of an exact power of two is exact in f64; guard the rounding of ceil() anyway
+    e = torch.where((amax > 0) & (torch.pow(2.0, e - 1) * 448.0 >= amax), e - 1, e).clamp(-127, 127)
+    scaled = (b * torch.pow(2.0, -e)[..., None]).float()
+    q = scaled.to(torch.float8_e4m3fn)
+    deq = q.double() * torch.pow(2.0, e)[..., None]
+    return q.view(torch.uint8).view(rows, K), (e + 127).to(torch.uint8), deq.view(rows, K)
+
+
+@pytest.mark.parametrize("rows,K", [(64, 128), (197, 1024), (1000, 768)])
+def test_quant_mxfp8_matches_emulation(yv, rows, K):
+    g = torch.Generator().manual_seed(rows + K)
+    x = (torch.randn(rows, K, generator=g) * torch.exp(torch.randn(rows, 1, generator=g) * 2)).to(torch.bfloat16)
+    x[3, :32] = 0                                            # an all-zero block
+    x[5, 32:64] = 448.0                                      # exactly the format maximum
+    x[6, 64:96] = 2.0 ** -20
+    qb, sb, _ = emulate_quant(x.float())
+    q, s = yv.quant_mxfp8(x.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(s.cpu(), sb)
+    assert torch.equal(q.cpu(), qb)
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(256, 256, 256, "f32"), (1000, 384, 1024, "f32"), (197 * 4, 1024, 1024, "bf16_bias"),
+                                        (640, 512, 4096, "gelu"), (130, 128, 128, "res")])
+def test_linear_mxfp8_matches_dequantised_product(yv, M, N, K, kind):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    _, _, ad = emulate_quant(a.float())
+    _, _, wd = emulate_quant(w.float())
+    aq, asc = yv.quant_mxfp8(a.to(DEV))
+    wq, wsc = yv.quant_mxfp8(w.to(DEV))
+    ref = ad @ wd.t()
+    if kind == "f32":
+        out = torch.zeros(M, N, device=DEV)
+        yv.linear_mxfp8(aq, asc, wq, wsc, None, out, flags=yv.EPI_OUT_F32)
+        torch.cuda.synchronize()
+        assert torch.allclose(out.cpu().double(), ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    elif kind == "res":
+        x = torch.randn(M, N, generator=g)
+        out = x.clone().to(DEV)
+        yv.linear_mxfp8(aq, asc, wq, wsc, bias.to(DEV), out, flags=yv.EPI_RES_F32)
+        torch.cuda.synchronize()
+        exp = x.double() + ref + bias.double()
+        assert torch.allclose(out.cpu().double(), exp, rtol=2e-5, atol=2e-5 * float(exp.abs().max()))
+    else:
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        yv.linear_mxfp8(aq, asc, wq, wsc, bias.to(DEV), out, flags=yv.EPI_GELU if kind == "gelu" else 0)
+        torch.cuda.synchronize()
+        exp = (ref + bias.double()).float()
+        exp = F.gelu(exp) if kind == "gelu" else exp
+        err = float((out.cpu().float() - exp).norm() / exp.norm())
+        assert err < 4e-3, err                                # bf16 output rounding
+    # and the quantisation itself is a small perturbation of the bf16 product (MX blocks of 32, e4m3)
+    full = a.double() @ w.double().t()
+    assert float((ref - full).norm() / full.norm()) < 5e-2

@@ -665,6 +665,202 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
 
 
 // ---------------------------------------------------------------------------------------------
+// MXFP8 variant of the LDS-DMA GEMM (BASELINE.json configs[4]: FP8 classifier GEMMs).  Operands are OCP e4m3 bytes
+// with one E8M0 scale per 32 consecutive K elements of a row (the OCP "MX" block format); the block-scaled
+// v_mfma_scale_f32_16x16x128_f8f6f4 applies both scales in hardware and runs at twice the bf16 MFMA rate.  A 128-byte LDS
+// row holds 128 K elements (one MFMA K step), so tile shape, DMA, swizzle and epilogues are those of gemm_dma_kernel:
+// the L2->LDS traffic per flop - what bounds the bf16 main loop - is halved.
+//   operand layout (measured with yv_mx_probe, tests/test_gpu_fp8.py::test_mx_mfma_layout): lane l = (row l&15, group
+//   g = l>>4) holds K elements 16g..16g+15 in its first 16 bytes and 64+16g..64+16g+15 in its second 16 bytes, i.e. the
+//   16-byte chunks g and 4+g of the 128-byte row; the scale of the MX block k = 32j..32j+31 of that row is byte `opsel`
+//   of the scale VGPR of lane (row, group j) - so lane (row, g) loads the scale of block g of the current K step.
+// Scales are read with ordinary byte loads one K step ahead (issued behind the DMA of that step, consumed after the
+// step's vmcnt(0)), so they never add a wait of their own.
+// ---------------------------------------------------------------------------------------------
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+struct MxArgs {
+    GemmArgs g;                 // a0 / w point at the fp8 bytes (row strides lda0 / K bytes); epilogue fields as usual
+    const uint8_t* sa;          // (M, K/32) E8M0
+    const uint8_t* sw;          // (N, K/32)
+};
+
+__global__ __launch_bounds__(256) void gemm_mx_kernel(MxArgs a) {
+    const GemmArgs& g = a.g;
+    constexpr int BM = 128, BN = 128, NW = 4, MF = 4, NF = 4, A_BYTES = BM * 128, W_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int M = g.M;
+    if (g.m_dev) { long long md = (long long)g.m_dev[0] * g.m_mul; M = md < M ? (int)md : M; }
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    int tm, tn;
+    {
+        const int GM = g.group_m, per = GM * g.tiles_n;
+        const int grp = bid / per, first = grp * GM;
+        const int gsz = (g.tiles_m - first) < GM ? (g.tiles_m - first) : GM;
+        const int in = bid - grp * per;
+        tm = first + in % gsz;
+        tn = in / gsz;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= M) return;
+    const int lrow = lane >> 3, lch = lane & 7;
+    const uint8_t* a_src[4];
+    const uint8_t* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * NW + wave) * 8 + lrow;
+        int m = m0 + r; m = m < g.M ? m : g.M - 1;
+        int n = n0 + r; n = n < g.N ? n : g.N - 1;
+        a_src[j] = (const uint8_t*)g.a0 + (long long)m * g.lda0 + ((lch ^ (r & 7)) << 4);
+        w_src[j] = (const uint8_t*)g.w + (long long)n * g.K + ((lch ^ (r & 7)) << 4);
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* A = smem + buf * (A_BYTES + W_BYTES);
+        unsigned char* W = A + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + kt * 128), (lptr_t)(A + (j * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + kt * 128), (lptr_t)(W + (j * NW + wave) * 1024), 16, 0, 0);
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wrow_m = wm * 64, wrow_n = wn * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int kb = g.K >> 5;                                   // scale blocks per row
+    const uint8_t* sa_p[MF];
+    const uint8_t* sw_p[NF];
+#pragma unroll
+    for (int j = 0; j < MF; ++j) {
+        int m = m0 + wrow_m + j * 16 + fr; m = m < g.M ? m : g.M - 1;
+        sa_p[j] = a.sa + (long long)m * kb + fq;
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        int n = n0 + wrow_n + i * 16 + fr; n = n < g.N ? n : g.N - 1;
+        sw_p[i] = a.sw + (long long)n * kb + fq;
+    }
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int sca[MF], scw[NF], sna[MF], snw[NF];
+    const int nk = g.K >> 7;
+    issue(0, 0);
+#pragma unroll
+    for (int j = 0; j < MF; ++j) sca[j] = sa_p[j][0];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) scw[i] = sw_p[i][0];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            issue(kt + 1, cur ^ 1);
+#pragma unroll
+            for (int j = 0; j < MF; ++j) sna[j] = sa_p[j][(kt + 1) * 4];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) snw[i] = sw_p[i][(kt + 1) * 4];
+        }
+        const unsigned char* A = smem + cur * (A_BYTES + W_BYTES);
+        const unsigned char* W = A + A_BYTES;
+        i32x8 fa[MF], fw[NF];
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int rr = wrow_m + j * 16 + fr;
+            const u32x4 lo = *(const u32x4*)(A + rr * 128 + (((fq) ^ (rr & 7)) << 4));
+            const u32x4 hi = *(const u32x4*)(A + rr * 128 + (((4 + fq) ^ (rr & 7)) << 4));
+            fa[j] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int rr = wrow_n + i * 16 + fr;
+            const u32x4 lo = *(const u32x4*)(W + rr * 128 + (((fq) ^ (rr & 7)) << 4));
+            const u32x4 hi = *(const u32x4*)(W + rr * 128 + (((4 + fq) ^ (rr & 7)) << 4));
+            fw[i] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[i], fa[j], acc[i][j], 0, 0, 0, scw[i], 0, sca[j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MF; ++j) sca[j] = sna[j];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) scw[i] = snw[i];
+    }
+    finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
+}
+
+// one MFMA on caller-provided register images (layout probe used while bringing the MX path up; tests keep it as the
+// executable statement of the operand layout)
+__global__ __launch_bounds__(64) void mx_probe_kernel(const i32x8* __restrict__ a, const i32x8* __restrict__ b,
+                                                      const int* __restrict__ sa, const int* __restrict__ sb, int opsel,
+                                                      f32x4* __restrict__ d) {
+    const int l = threadIdx.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (opsel == 0) acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[l], b[l], acc, 0, 0, 0, sa[l], 0, sb[l]);
+    else if (opsel == 1) acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[l], b[l], acc, 0, 0, 1, sa[l], 1, sb[l]);
+    else if (opsel == 2) acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[l], b[l], acc, 0, 0, 2, sa[l], 2, sb[l]);
+    else acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[l], b[l], acc, 0, 0, 3, sa[l], 3, sb[l]);
+    d[l] = acc;
+}
+
+// x (rows, K) bf16 -> q (rows, K) e4m3 bytes + scales (rows, K/32) E8M0: scale exponent e = ceil(log2(amax / 448)) of the
+// 32-element block (so that amax * 2^-e <= 448), all-zero blocks get e = -127; q = RNE_e4m3(x * 2^-e)
+__global__ __launch_bounds__(256) void quant_mx_kernel(const uint16_t* __restrict__ x, long long ldx, long long rows, int K,
+                                                       uint8_t* __restrict__ q, long long ldq, uint8_t* __restrict__ sc) {
+    const int kb = K >> 5;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * kb) return;
+    const long long r = idx / kb;
+    const int b = (int)(idx - r * kb);
+    const uint16_t* src = x + r * ldx + b * 32;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint4 u = *(const uint4*)(src + c * 8);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[c * 8 + 2 * i] = bf16_to_f32((uint16_t)(w[i] & 0xffff));
+            v[c * 8 + 2 * i + 1] = bf16_to_f32((uint16_t)(w[i] >> 16));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    int e = -127;
+    if (amax > 0.f) {
+        int ex;
+        const float mant = frexpf(amax * (1.0f / 448.0f), &ex);          // amax/448 = mant * 2^ex, mant in [0.5, 1)
+        e = mant == 0.5f ? ex - 1 : ex;                                   // ceil(log2(amax/448))
+        e = e < -127 ? -127 : (e > 127 ? 127 : e);
+    }
+    const float inv = ldexpf(1.0f, -e);
+    uint32_t out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int p = 0;
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i] * inv, v[4 * i + 1] * inv, p, false);
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i + 2] * inv, v[4 * i + 3] * inv, p, true);
+        out[i] = (uint32_t)p;
+    }
+    uint4* dst = (uint4*)(q + r * ldq + b * 32);
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    sc[r * kb + b] = (uint8_t)(e + 127);
+}
+
+// ---------------------------------------------------------------------------------------------
 // 256 x 256 x 64 "8-phase" kernel (cdna_hip_programming.md section 5 template, re-derived for this operand
 // convention).  8 waves = 2 groups (wm = 0/1, 128 activation rows each) x 4 (64 weight rows each); one
 // workgroup per CU, 128 KB of LDS = 2 stages x {A tile, W tile}.  A K tile is consumed in 4 phases, one
@@ -1019,6 +1215,46 @@ extern "C" int yv_set_workspace(void* stream, void* ws, size_t bytes) {
     if (!ws || !bytes) g_ws.erase(stream);
     else g_ws[stream] = std::make_pair(ws, bytes);
     return YV_OK;
+}
+
+extern "C" int yv_mx_probe(const void* a, const void* b, const void* sa, const void* sb, int opsel, void* d, void* stream) {
+    if (!a || !b || !sa || !sb || !d || opsel < 0 || opsel > 3) return YV_ERR_ARG;
+    hipLaunchKernelGGL(mx_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const i32x8*)a, (const i32x8*)b,
+                       (const int*)sa, (const int*)sb, opsel, (f32x4*)d);
+    return yv_launch_status();
+}
+
+extern "C" int yv_quant_mxfp8(const void* x, long long ldx, long long rows, int K, void* q, long long ldq, void* scales,
+                              void* stream) {
+    if (!x || !q || !scales || rows <= 0 || K <= 0 || (K & 31) || (ldx & 7) || (ldq & 15)) return YV_ERR_ARG;
+    if (((uintptr_t)x | (uintptr_t)q) & 15) return YV_ERR_ARG;
+    const long long items = rows * (K >> 5);
+    hipLaunchKernelGGL(quant_mx_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, ldx, rows, K, (uint8_t*)q, ldq, (uint8_t*)scales);
+    return yv_launch_status();
+}
+
+extern "C" int yv_linear_mxfp8(const void* Aq, long long lda, const void* Ascale, const void* Wq, const void* Wscale,
+                               const float* bias, int M, int N, int K, void* out, int ldo, int flags, const int32_t* m_dev,
+                               int m_mul, void* stream) {
+    if (!Aq || !Ascale || !Wq || !Wscale || !out || M < 0 || N <= 0 || K <= 0) return YV_ERR_ARG;
+    if ((K & 127) || (lda & 15) || (N & 7) || (ldo & 7)) return YV_ERR_ARG;             // whole 128-element K steps
+    if ((flags & YV_EPI_BIAS) && !bias) return YV_ERR_ARG;
+    if (flags & ~(YV_EPI_BIAS | YV_EPI_GELU | YV_EPI_RES_F32 | YV_EPI_OUT_F32)) return YV_ERR_ARG;
+    if (((uintptr_t)Aq | (uintptr_t)Wq | (uintptr_t)out) & 15) return YV_ERR_ARG;
+    if (M == 0) return YV_OK;
+    MxArgs a = {};
+    GemmArgs& g = a.g;
+    g.a0 = (const uint16_t*)Aq; g.lda0 = (int)lda; g.w = (const uint16_t*)Wq; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.out = out; g.ldo = ldo; g.flags = flags; g.m_dev = m_dev; g.m_mul = m_mul;
+    g.ksize = 1; g.stride = 1; g.splitk = 1;
+    g.staged = epi_can_stage(g);
+    if (!g.staged) return YV_ERR_ARG;
+    g.group_m = g_opt_group_m > 0 ? g_opt_group_m : 8;
+    g.tiles_m = (M + 127) / 128; g.tiles_n = (N + 127) / 128;
+    a.sa = (const uint8_t*)Ascale; a.sw = (const uint8_t*)Wscale;
+    hipLaunchKernelGGL(gemm_mx_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), 65536, (hipStream_t)stream, a);
+    return yv_launch_status();
 }
 
 extern "C" int yv_set_launch_timing(void* start_event, void* stop_event) {

@@ -54,6 +54,9 @@ _SIGS = {
     "yv_set_option": (_i, [C.c_char_p, _i]),
     "yv_set_workspace": (_i, [_vp, _vp, _sz]),
     "yv_set_launch_timing": (_i, [_vp, _vp]),
+    "yv_mx_probe": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "yv_quant_mxfp8": (_i, [_vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, _vp, _vp]),
+    "yv_linear_mxfp8": (_i, [_vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "yv_custom_nms_ws_bytes": (_sz, [_i, _i]),
     "yv_custom_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "yv_efficient_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -678,3 +681,27 @@ def ema_update(ema: torch.Tensor, src: torch.Tensor, decay: float):
 def axpby(dst: torch.Tensor, src: torch.Tensor, a: float, b: float):
     _chk_dev(dst, src)
     check(lib.yv_axpby(_p(dst), _p(src), dst.numel(), float(a), float(b), _st()), "yv_axpby")
+
+
+# ------------------------------------------------------------- MXFP8 linears (BASELINE configs[4])
+def quant_mxfp8(x: torch.Tensor, q: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None):
+    """x (rows, K) bf16 -> (q (rows, K) uint8 e4m3 bytes, scales (rows, K/32) uint8 E8M0)."""
+    _chk_dev(x, q, scales)
+    rows, K = x.shape
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device) if q is None else q
+    scales = torch.empty((rows, K // 32), dtype=torch.uint8, device=x.device) if scales is None else scales
+    check(lib.yv_quant_mxfp8(_p(x), x.stride(0), rows, K, _p(q), q.stride(0), _p(scales), _st()), "yv_quant_mxfp8")
+    return q, scales
+
+
+def linear_mxfp8(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
+                 bias: Optional[torch.Tensor], out: torch.Tensor, flags: int = 0, m_dev: Optional[torch.Tensor] = None,
+                 m_mul: int = 1):
+    _chk_dev(aq, a_scale, wq, w_scale, bias, out, m_dev)
+    M, K = aq.shape
+    N = wq.shape[0]
+    if bias is not None:
+        flags |= EPI_BIAS
+    check(lib.yv_linear_mxfp8(_p(aq), aq.stride(0), _p(a_scale), _p(wq), _p(w_scale), _p(bias), M, N, K, _p(out),
+                              out.stride(0), flags, _p(m_dev), m_mul, _st()), "yv_linear_mxfp8")
+    return out
