@@ -44,17 +44,21 @@ int yv_set_option(const char* key, int value);
 
 /* MXFP8 linears (BASELINE.json configs[4], FP8 classifier GEMMs; OCP e4m3 bytes + one E8M0 scale per 32 consecutive K
  * elements of a row, consumed by the block-scaled gfx950 MFMA).
- * yv_quant_mxfp8: x (rows, K) bf16 -> q (rows, K) bytes (row stride ldq) + scales (rows, K/32); scale exponent
- *   e = ceil(log2(amax/448)) per block, q = RNE_e4m3(x * 2^-e); K a multiple of 32.
+ * Scale arrays are K-step-major: (K/128, rows_pad, 4) bytes - the four block scales of one 128-deep K step of a row form
+ * one dword, a tile's 128 dwords are contiguous (one LDS-DMA half); rows_pad = row count rounded up to 128.
+ * yv_quant_mxfp8: x (rows, K) bf16 -> q (rows, K) bytes (row stride ldq) + scales; scale exponent
+ *   e = ceil(log2(amax/448)) per block, q = RNE_e4m3(x * 2^-e); K a multiple of 128.
  * yv_linear_mxfp8: out[M,N] = (Aq*2^sa)[M,K] . (Wq*2^sw)[N,K]^T with the epilogues of yv_linear (bias, GELU, f32 residual
- *   read-modify-write, f32 output); K a multiple of 128. */
+ *   read-modify-write, f32 output). */
 /* Diagnostic: ONE v_mfma_scale_f32_16x16x128_f8f6f4 on caller-provided register images: a, b (64 lanes x 32 bytes),
  * sa, sb (64 x int32 scale registers), opsel 0..3 for both; d (64 lanes x 4 f32). */
 int yv_mx_probe(const void* a, const void* b, const void* sa, const void* sb, int opsel, void* d, void* stream);
 
-int yv_quant_mxfp8(const void* x, long long ldx, long long rows, int K, void* q, long long ldq, void* scales, void* stream);
-int yv_linear_mxfp8(const void* Aq, long long lda, const void* Ascale, const void* Wq, const void* Wscale, const float* bias,
-                    int M, int N, int K, void* out, int ldo, int flags, const int32_t* m_dev, int m_mul, void* stream);
+int yv_quant_mxfp8(const void* x, long long ldx, long long rows, int K, void* q, long long ldq, void* scales,
+                   long long rows_pad, void* stream);
+int yv_linear_mxfp8(const void* Aq, long long lda, const void* Ascale, long long a_rows_pad, const void* Wq, const void* Wscale,
+                    long long w_rows_pad, const float* bias, int M, int N, int K, void* out, int ldo, int flags,
+                    const int32_t* m_dev, int m_mul, void* stream);
 
 /* Measurement hook (bench.py): the NEXT LDS-DMA GEMM launch issued by the calling thread (yv_linear / yv_linear_ex /
  * yv_linear_nn) records its start / stop timestamps into these hipEvent_t handles through hipExtLaunchKernel, i.e. from

@@ -681,13 +681,15 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 struct MxArgs {
     GemmArgs g;                 // a0 / w point at the fp8 bytes (row strides lda0 / K bytes); epilogue fields as usual
-    const uint8_t* sa;          // (M, K/32) E8M0
-    const uint8_t* sw;          // (N, K/32)
+    const uint8_t* sa;          // E8M0 scales, K-step-major: (K/128, rows_a, 4) - the 4 blocks of one 128-deep K step of a row
+    const uint8_t* sw;          // (K/128, rows_w, 4)                               are one aligned dword
+    long long rows_a, rows_w;   // row counts of the scale arrays (multiples of 128: a tile's 128 dwords are one DMA half)
 };
 
 __global__ __launch_bounds__(256) void gemm_mx_kernel(MxArgs a) {
     const GemmArgs& g = a.g;
     constexpr int BM = 128, BN = 128, NW = 4, MF = 4, NF = 4, A_BYTES = BM * 128, W_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + W_BYTES + 1024;            // + 512 B of A scales + 512 B of W scales
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int M = g.M;
@@ -719,8 +721,11 @@ __global__ __launch_bounds__(256) void gemm_mx_kernel(MxArgs a) {
         a_src[j] = (const uint8_t*)g.a0 + (long long)m * g.lda0 + ((lch ^ (r & 7)) << 4);
         w_src[j] = (const uint8_t*)g.w + (long long)n * g.K + ((lch ^ (r & 7)) << 4);
     }
+    // scale DMA (wave 0 only): lanes 0..31 fetch the tile's 128 A dwords (4 rows per lane), lanes 32..63 the W dwords
+    const uint8_t* s_src = lane < 32 ? a.sa + ((long long)m0 + 4 * lane) * 4 : a.sw + ((long long)n0 + 4 * (lane - 32)) * 4;
+    const long long s_step = (lane < 32 ? a.rows_a : a.rows_w) * 4;
     auto issue = [&](int kt, int buf) {
-        unsigned char* A = smem + buf * (A_BYTES + W_BYTES);
+        unsigned char* A = smem + buf * STAGE;
         unsigned char* W = A + A_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -728,55 +733,36 @@ __global__ __launch_bounds__(256) void gemm_mx_kernel(MxArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + kt * 128), (lptr_t)(W + (j * NW + wave) * 1024), 16, 0, 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((gptr_t)(s_src + kt * s_step), (lptr_t)(W + W_BYTES), 16, 0, 0);
     };
     const int wm = wave >> 1, wn = wave & 1;
     const int wrow_m = wm * 64, wrow_n = wn * 64;
     const int fr = lane & 15, fq = lane >> 4;
-    const int kb = g.K >> 5;                                   // scale blocks per row
-    const uint8_t* sa_p[MF];
-    const uint8_t* sw_p[NF];
-#pragma unroll
-    for (int j = 0; j < MF; ++j) {
-        int m = m0 + wrow_m + j * 16 + fr; m = m < g.M ? m : g.M - 1;
-        sa_p[j] = a.sa + (long long)m * kb + fq;
-    }
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        int n = n0 + wrow_n + i * 16 + fr; n = n < g.N ? n : g.N - 1;
-        sw_p[i] = a.sw + (long long)n * kb + fq;
-    }
     f32x4 acc[NF][MF];
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
         for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int sca[MF], scw[NF], sna[MF], snw[NF];
     const int nk = g.K >> 7;
     issue(0, 0);
-#pragma unroll
-    for (int j = 0; j < MF; ++j) sca[j] = sa_p[j][0];
-#pragma unroll
-    for (int i = 0; i < NF; ++i) scw[i] = sw_p[i][0];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            issue(kt + 1, cur ^ 1);
-#pragma unroll
-            for (int j = 0; j < MF; ++j) sna[j] = sa_p[j][(kt + 1) * 4];
-#pragma unroll
-            for (int i = 0; i < NF; ++i) snw[i] = sw_p[i][(kt + 1) * 4];
-        }
-        const unsigned char* A = smem + cur * (A_BYTES + W_BYTES);
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        const unsigned char* A = smem + cur * STAGE;
         const unsigned char* W = A + A_BYTES;
+        const unsigned char* S = W + W_BYTES;
         i32x8 fa[MF], fw[NF];
+        int sca[MF], scw[NF];
 #pragma unroll
         for (int j = 0; j < MF; ++j) {
             const int rr = wrow_m + j * 16 + fr;
             const u32x4 lo = *(const u32x4*)(A + rr * 128 + (((fq) ^ (rr & 7)) << 4));
             const u32x4 hi = *(const u32x4*)(A + rr * 128 + (((4 + fq) ^ (rr & 7)) << 4));
             fa[j] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            sca[j] = (int)(*(const uint32_t*)(S + rr * 4) >> (8 * fq));              // byte 0 = scale of block fq
         }
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
@@ -784,6 +770,7 @@ __global__ __launch_bounds__(256) void gemm_mx_kernel(MxArgs a) {
             const u32x4 lo = *(const u32x4*)(W + rr * 128 + (((fq) ^ (rr & 7)) << 4));
             const u32x4 hi = *(const u32x4*)(W + rr * 128 + (((4 + fq) ^ (rr & 7)) << 4));
             fw[i] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            scw[i] = (int)(*(const uint32_t*)(S + 512 + rr * 4) >> (8 * fq));
         }
 #pragma unroll
         for (int i = 0; i < NF; ++i)
@@ -792,10 +779,6 @@ __global__ __launch_bounds__(256) void gemm_mx_kernel(MxArgs a) {
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[i], fa[j], acc[i][j], 0, 0, 0, scw[i], 0, sca[j]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < MF; ++j) sca[j] = sna[j];
-#pragma unroll
-        for (int i = 0; i < NF; ++i) scw[i] = snw[i];
     }
     finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
 }
@@ -817,7 +800,8 @@ __global__ __launch_bounds__(64) void mx_probe_kernel(const i32x8* __restrict__ 
 // x (rows, K) bf16 -> q (rows, K) e4m3 bytes + scales (rows, K/32) E8M0: scale exponent e = ceil(log2(amax / 448)) of the
 // 32-element block (so that amax * 2^-e <= 448), all-zero blocks get e = -127; q = RNE_e4m3(x * 2^-e)
 __global__ __launch_bounds__(256) void quant_mx_kernel(const uint16_t* __restrict__ x, long long ldx, long long rows, int K,
-                                                       uint8_t* __restrict__ q, long long ldq, uint8_t* __restrict__ sc) {
+                                                       uint8_t* __restrict__ q, long long ldq, uint8_t* __restrict__ sc,
+                                                       long long rows_pad) {
     const int kb = K >> 5;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * kb) return;
@@ -857,7 +841,7 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const uint16_t* __restric
     uint4* dst = (uint4*)(q + r * ldq + b * 32);
     dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
     dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
-    sc[r * kb + b] = (uint8_t)(e + 127);
+    sc[((long long)(b >> 2) * rows_pad + r) * 4 + (b & 3)] = (uint8_t)(e + 127);      // (K/128, rows_pad, 4)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1225,20 +1209,23 @@ extern "C" int yv_mx_probe(const void* a, const void* b, const void* sa, const v
 }
 
 extern "C" int yv_quant_mxfp8(const void* x, long long ldx, long long rows, int K, void* q, long long ldq, void* scales,
-                              void* stream) {
-    if (!x || !q || !scales || rows <= 0 || K <= 0 || (K & 31) || (ldx & 7) || (ldq & 15)) return YV_ERR_ARG;
+                              long long rows_pad, void* stream) {
+    if (!x || !q || !scales || rows <= 0 || K <= 0 || (K & 127) || (ldx & 7) || (ldq & 15)) return YV_ERR_ARG;
+    if (rows_pad < rows || (rows_pad & 127)) return YV_ERR_ARG;
     if (((uintptr_t)x | (uintptr_t)q) & 15) return YV_ERR_ARG;
     const long long items = rows * (K >> 5);
     hipLaunchKernelGGL(quant_mx_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)x, ldx, rows, K, (uint8_t*)q, ldq, (uint8_t*)scales);
+                       (const uint16_t*)x, ldx, rows, K, (uint8_t*)q, ldq, (uint8_t*)scales, rows_pad);
     return yv_launch_status();
 }
 
-extern "C" int yv_linear_mxfp8(const void* Aq, long long lda, const void* Ascale, const void* Wq, const void* Wscale,
-                               const float* bias, int M, int N, int K, void* out, int ldo, int flags, const int32_t* m_dev,
-                               int m_mul, void* stream) {
+extern "C" int yv_linear_mxfp8(const void* Aq, long long lda, const void* Ascale, long long a_rows_pad, const void* Wq,
+                               const void* Wscale, long long w_rows_pad, const float* bias, int M, int N, int K, void* out,
+                               int ldo, int flags, const int32_t* m_dev, int m_mul, void* stream) {
     if (!Aq || !Ascale || !Wq || !Wscale || !out || M < 0 || N <= 0 || K <= 0) return YV_ERR_ARG;
     if ((K & 127) || (lda & 15) || (N & 7) || (ldo & 7)) return YV_ERR_ARG;             // whole 128-element K steps
+    if (a_rows_pad < M || (a_rows_pad & 127) || w_rows_pad < N || (w_rows_pad & 127)) return YV_ERR_ARG;
+    if (((uintptr_t)Ascale | (uintptr_t)Wscale) & 15) return YV_ERR_ARG;
     if ((flags & YV_EPI_BIAS) && !bias) return YV_ERR_ARG;
     if (flags & ~(YV_EPI_BIAS | YV_EPI_GELU | YV_EPI_RES_F32 | YV_EPI_OUT_F32)) return YV_ERR_ARG;
     if (((uintptr_t)Aq | (uintptr_t)Wq | (uintptr_t)out) & 15) return YV_ERR_ARG;
@@ -1252,8 +1239,11 @@ extern "C" int yv_linear_mxfp8(const void* Aq, long long lda, const void* Ascale
     if (!g.staged) return YV_ERR_ARG;
     g.group_m = g_opt_group_m > 0 ? g_opt_group_m : 8;
     g.tiles_m = (M + 127) / 128; g.tiles_n = (N + 127) / 128;
-    a.sa = (const uint8_t*)Ascale; a.sw = (const uint8_t*)Wscale;
-    hipLaunchKernelGGL(gemm_mx_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), 65536, (hipStream_t)stream, a);
+    a.sa = (const uint8_t*)Ascale; a.sw = (const uint8_t*)Wscale; a.rows_a = a_rows_pad; a.rows_w = w_rows_pad;
+    const size_t lds = 2 * (size_t)(128 * 128 * 2 + 1024);
+    if (hipFuncSetAttribute((const void*)gemm_mx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return YV_ERR_LAUNCH;
+    hipLaunchKernelGGL(gemm_mx_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, (hipStream_t)stream, a);
     return yv_launch_status();
 }
 

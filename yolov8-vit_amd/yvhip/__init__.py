@@ -55,8 +55,9 @@ _SIGS = {
     "yv_set_workspace": (_i, [_vp, _vp, _sz]),
     "yv_set_launch_timing": (_i, [_vp, _vp]),
     "yv_mx_probe": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "yv_quant_mxfp8": (_i, [_vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, _vp, _vp]),
-    "yv_linear_mxfp8": (_i, [_vp, C.c_longlong, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "yv_quant_mxfp8": (_i, [_vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, _vp, C.c_longlong, _vp]),
+    "yv_linear_mxfp8": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, _vp, _vp, C.c_longlong, _vp, _i, _i, _i, _vp, _i, _i, _vp,
+                             _i, _vp]),
     "yv_custom_nms_ws_bytes": (_sz, [_i, _i]),
     "yv_custom_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "yv_efficient_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -685,12 +686,14 @@ def axpby(dst: torch.Tensor, src: torch.Tensor, a: float, b: float):
 
 # ------------------------------------------------------------- MXFP8 linears (BASELINE configs[4])
 def quant_mxfp8(x: torch.Tensor, q: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None):
-    """x (rows, K) bf16 -> (q (rows, K) uint8 e4m3 bytes, scales (rows, K/32) uint8 E8M0)."""
+    """x (rows, K) bf16 -> (q (rows, K) uint8 e4m3 bytes, scales (K/128, rows_pad, 4) uint8 E8M0, rows_pad = rows up to 128)."""
     _chk_dev(x, q, scales)
     rows, K = x.shape
+    rp = (rows + 127) // 128 * 128
     q = torch.empty((rows, K), dtype=torch.uint8, device=x.device) if q is None else q
-    scales = torch.empty((rows, K // 32), dtype=torch.uint8, device=x.device) if scales is None else scales
-    check(lib.yv_quant_mxfp8(_p(x), x.stride(0), rows, K, _p(q), q.stride(0), _p(scales), _st()), "yv_quant_mxfp8")
+    scales = torch.zeros((K // 128, rp, 4), dtype=torch.uint8, device=x.device) if scales is None else scales
+    check(lib.yv_quant_mxfp8(_p(x), x.stride(0), rows, K, _p(q), q.stride(0), _p(scales), scales.shape[1], _st()),
+          "yv_quant_mxfp8")
     return q, scales
 
 
@@ -702,6 +705,6 @@ def linear_mxfp8(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_sc
     N = wq.shape[0]
     if bias is not None:
         flags |= EPI_BIAS
-    check(lib.yv_linear_mxfp8(_p(aq), aq.stride(0), _p(a_scale), _p(wq), _p(w_scale), _p(bias), M, N, K, _p(out),
-                              out.stride(0), flags, _p(m_dev), m_mul, _st()), "yv_linear_mxfp8")
+    check(lib.yv_linear_mxfp8(_p(aq), aq.stride(0), _p(a_scale), a_scale.shape[1], _p(wq), _p(w_scale), w_scale.shape[1],
+                              _p(bias), M, N, K, _p(out), out.stride(0), flags, _p(m_dev), m_mul, _st()), "yv_linear_mxfp8")
     return out
