@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--models", choices=["base", "large"], default="base",
                     help="base = YOLOv8n + ViT-B/16 (configs[1], the headline); large = YOLOv8m + ViT-L/16 in bf16 "
                          "(the model pair of configs[4]; its FP8 arithmetic is not built, so this is NOT that config's number)")
+    ap.add_argument("--dtype", choices=["bf16", "mxfp8"], default="bf16",
+                    help="arithmetic of the classifier's block linears; mxfp8 = OCP e4m3 + E8M0 block scales (configs[4]); the "
+                         "headline metric is defined on bf16")
     ap.add_argument("--mode", choices=["infer", "train", "train-yolo"], default="infer",
                     help="infer = headline metric (configs[1]); train = ViT-B/16 fine-tune step (configs[2]); "
                          "train-yolo = YOLOv8s training step (configs[3])")
@@ -181,7 +184,7 @@ def main():
     yolo_sd = engines.init_yolo_state(yscale, 5, seed=42, head_gain=4.0)
     vit_sd = engines.init_vit_wrapper_state(vit_name, 5, seed=42)
     yolo = engines.YoloEngine(yolo_sd, yscale, 5, 640, device=str(dev))
-    vit = engines.VitEngine(vit_sd, vit_name, 5, device=str(dev))
+    vit = engines.VitEngine(vit_sd, vit_name, 5, device=str(dev), dtype=args.dtype)
     B, R = args.batch, args.crops
     pipe = DetectClassifyPipeline(yolo, [vit], max_crops_per_image=R)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -253,9 +256,10 @@ def main():
             "metric": "images/sec end-to-end (640->224 detect+classify)",
             "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("YOLOv8m(nc=5)+ViT-L/16 end-to-end inference, 640x640, bf16 (model pair of BASELINE.json "
-                                    "configs[4]; FP8 not built)") if large else
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "mxfp8 (classifier block linears) + bf16",
+            "data": "synthetic",
+            "config": {"workload": ("YOLOv8m(nc=5)+ViT-L/16 end-to-end inference, 640x640 (model pair of BASELINE.json "
+                                    "configs[4]); classifier block linears in " + args.dtype) if large else
                                    ("YOLOv8n(nc=5)+ViT-B/16 end-to-end inference, 640x640, bf16 "
                                     "(BASELINE.json configs[1])"), "batch_per_gpu": B, "global_batch": B * world,
                        "crops_per_image": R, "crops_per_step_rank0": crops_step, "parallelism": f"dp{world}",

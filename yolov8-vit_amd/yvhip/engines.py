@@ -18,7 +18,8 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import (EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, cls_rows,
-               conv2d, detect_decode, layernorm, linear, require_gpu, sppf_pool, stem_conv, view, wrapper_head)
+               conv2d, detect_decode, layernorm, linear, linear_mxfp8, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
+               wrapper_head)
 
 # --------------------------------------------------------------------------------------- YOLOv8
 YOLO_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768)}
@@ -304,8 +305,15 @@ class VitEngine:
     through the Network_Wrapper head, class logits (cap, nc) + labels (cap)."""
 
     def __init__(self, state: Dict[str, torch.Tensor], name: str, num_classes: int = 5, img: int = 224,
-                 device: str = "cuda:0"):
+                 device: str = "cuda:0", dtype: str = "bf16"):
+        """dtype "bf16" (default) or "mxfp8": the four block linears (qkv, proj, fc1, fc2) then run on OCP e4m3 operands
+        with one E8M0 scale per 32 K elements through the block-scaled MFMA (BASELINE.json configs[4]); weights are
+        quantised once here, activations by yv_quant_mxfp8 in front of each GEMM; everything else (patch-embed, LayerNorm,
+        attention, residual stream, heads) keeps its bf16 / f32 form."""
         require_gpu()
+        if dtype not in ("bf16", "mxfp8"):
+            raise YvError("dtype must be 'bf16' or 'mxfp8'")
+        self.dtype = dtype
         self.P, self.D, self.L, self.H = vit_cfg(name)
         if self.D // self.H != 64:
             raise YvError("attention kernel is specialised for head dim 64")
@@ -330,6 +338,13 @@ class VitEngine:
                 n2w=f32(g(p + "norm2.weight")), n2b=f32(g(p + "norm2.bias")),
                 wfc1=bf(g(p + "mlp.fc1.weight")), bfc1=f32(g(p + "mlp.fc1.bias")),
                 wfc2=bf(g(p + "mlp.fc2.weight")), bfc2=f32(g(p + "mlp.fc2.bias"))))
+        if dtype == "mxfp8":
+            if D % 128:
+                raise YvError("mxfp8 needs an embedding width that is a multiple of 128")
+            for blk in self.blocks:
+                for k in ("wqkv", "wproj", "wfc1", "wfc2"):
+                    blk[k + "_q"], blk[k + "_s"] = quant_mxfp8(blk[k])
+                    del blk[k]
         self.nw, self.nb = f32(g("norm.weight")), f32(g("norm.bias"))
         wh = torch.zeros(1024, D)
         wh[:1000] = g("head.weight").float()
@@ -352,6 +367,9 @@ class VitEngine:
                 x=z((cap * N, D), torch.float32), h=z((cap * N, D), torch.bfloat16),
                 qkv=z((cap * N, 3 * D), torch.bfloat16), o=z((cap * N, D), torch.bfloat16),
                 g=z((cap * N, 4 * D), torch.bfloat16), c=z((cap, D), torch.bfloat16),
+                **({} if self.dtype != "mxfp8" else dict(
+                    q=z((cap * N, 4 * D), torch.uint8),                  # e4m3 image of the current GEMM input
+                    qs=z((4 * D // 128, (cap * N + 127) // 128 * 128, 4), torch.uint8))),
                 feats=z((cap, 1024), torch.float32))
         return self._bufs[key]
 
@@ -370,6 +388,8 @@ class VitEngine:
         linear(patches, self.w_pe, self.b_pe, x, flags=EPI_OUT_F32 | EPI_POSEMB, pos=self.pos, tok=tok, m_dev=count,
                m_mul=tok)
         rows = cap * N
+        if self.dtype == "mxfp8":
+            return self._backbone_mxfp8(b, cap, count)
         for blk in self.blocks:
             layernorm(x, blk["n1w"], blk["n1b"], h, rows, D, D, D, count_dev=count, rows_per_count=N)
             linear(h, blk["wqkv"], blk["bqkv"], qkv, m_dev=count, m_mul=N)
@@ -378,6 +398,30 @@ class VitEngine:
             layernorm(x, blk["n2w"], blk["n2b"], h, rows, D, D, D, count_dev=count, rows_per_count=N)
             linear(h, blk["wfc1"], blk["bfc1"], gbuf, flags=EPI_GELU, m_dev=count, m_mul=N)
             linear(gbuf, blk["wfc2"], blk["bfc2"], x, flags=EPI_RES_F32, m_dev=count, m_mul=N)
+        layernorm(x, self.nw, self.nb, b["c"], cap, D, N * D, D, count_dev=count, rows_per_count=1)
+        linear(b["c"], self.w_head, self.b_head, b["feats"], flags=EPI_OUT_F32, m_dev=count, m_mul=1)
+        return b["feats"]
+
+    def _backbone_mxfp8(self, b: dict, cap: int, count: Optional[torch.Tensor]) -> torch.Tensor:
+        D, N, H = self.D, self.N, self.H
+        x, h, qkv, o, gbuf = b["x"], b["h"], b["qkv"], b["o"], b["g"]
+        rows = cap * N
+        rp = b["qs"].shape[1]
+
+        def gemm(src, K, wq, ws, bias, out, flags):
+            aq = b["q"].view(-1)[:rows * K].view(rows, K)
+            asc = b["qs"].view(-1)[:(K // 128) * rp * 4].view(K // 128, rp, 4)
+            quant_mxfp8(src, aq, asc)
+            linear_mxfp8(aq, asc, wq, ws, bias, out, flags=flags, m_dev=count, m_mul=N)
+
+        for blk in self.blocks:
+            layernorm(x, blk["n1w"], blk["n1b"], h, rows, D, D, D, count_dev=count, rows_per_count=N)
+            gemm(h, D, blk["wqkv_q"], blk["wqkv_s"], blk["bqkv"], qkv, 0)
+            attention(qkv, cap, N, H, o, r_dev=count)
+            gemm(o, D, blk["wproj_q"], blk["wproj_s"], blk["bproj"], x, EPI_RES_F32)
+            layernorm(x, blk["n2w"], blk["n2b"], h, rows, D, D, D, count_dev=count, rows_per_count=N)
+            gemm(h, D, blk["wfc1_q"], blk["wfc1_s"], blk["bfc1"], gbuf, EPI_GELU)
+            gemm(gbuf, 4 * D, blk["wfc2_q"], blk["wfc2_s"], blk["bfc2"], x, EPI_RES_F32)
         layernorm(x, self.nw, self.nb, b["c"], cap, D, N * D, D, count_dev=count, rows_per_count=1)
         linear(b["c"], self.w_head, self.b_head, b["feats"], flags=EPI_OUT_F32, m_dev=count, m_mul=1)
         return b["feats"]
