@@ -50,6 +50,12 @@ int yv_set_option(const char* key, int value);
  *   e = ceil(log2(amax/448)) per block, q = RNE_e4m3(x * 2^-e); K a multiple of 128.
  * yv_linear_mxfp8: out[M,N] = (Aq*2^sa)[M,K] . (Wq*2^sw)[N,K]^T with the epilogues of yv_linear (bias, GELU, f32 residual
  *   read-modify-write, f32 output). */
+/* yv_layernorm with the output written directly in the MXFP8 operand format (same numbers as yv_layernorm followed by
+ * yv_quant_mxfp8: the bf16 rounding is kept); D a multiple of 128. */
+int yv_layernorm_mxfp8(const float* x, size_t ldx, const float* gamma, const float* beta, int rows, int D, float eps, void* q,
+                       size_t ldq, void* scales, long long rows_pad, const int32_t* count_dev, int rows_per_count,
+                       void* stream);
+
 /* Diagnostic: ONE v_mfma_scale_f32_16x16x128_f8f6f4 on caller-provided register images: a, b (64 lanes x 32 bytes),
  * sa, sb (64 x int32 scale registers), opsel 0..3 for both; d (64 lanes x 4 f32). */
 int yv_mx_probe(const void* a, const void* b, const void* sa, const void* sb, int opsel, void* d, void* stream);

@@ -142,3 +142,22 @@ def test_vit_engine_mxfp8_tracks_bf16(yv):
     assert err < 0.12, err
     assert float(cos.min()) > 0.99, float(cos.min())
     assert agree >= 0.5, agree             # 1000 near-tied random-init logits: the arg-max is a noisy statistic here (measured 0.75)
+
+
+def test_layernorm_mxfp8_equals_layernorm_then_quant(yv):
+    """The fused LayerNorm -> MXFP8 kernel keeps the bf16 rounding of the two-kernel path, so bytes and scales must be
+    identical to yv_layernorm followed by yv_quant_mxfp8 (device-side dynamic row count included)."""
+    g = torch.Generator().manual_seed(6)
+    rows, D = 394, 1024
+    x = (torch.randn(rows, D, generator=g) * 3 + 0.5).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV); beta = (0.1 * torch.randn(D, generator=g)).to(DEV)
+    cnt = torch.tensor([2], dtype=torch.int32, device=DEV)                      # 2 x 150 = 300 live rows
+    h = torch.zeros(rows, D, dtype=torch.bfloat16, device=DEV)
+    yv.layernorm(x, gamma, beta, h, rows, D, D, D, count_dev=cnt, rows_per_count=150)
+    q_ref, s_ref = yv.quant_mxfp8(h)
+    q = torch.zeros(rows, D, dtype=torch.uint8, device=DEV)
+    s = torch.zeros_like(s_ref)
+    yv.layernorm_mxfp8(x, gamma, beta, q, s, rows, D, D, count_dev=cnt, rows_per_count=150)
+    torch.cuda.synchronize()
+    assert torch.equal(q[:300], q_ref[:300]) and torch.equal(s[:, :300], s_ref[:, :300])
+    assert float(q[300:].float().abs().sum()) == 0                              # rows past the count stay untouched

@@ -59,6 +59,77 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// LayerNorm whose output goes straight to the MXFP8 operand format of yv_linear_mxfp8 (e4m3 bytes + one E8M0 scale per 32
+// consecutive elements): a block is 8 consecutive float4 chunks = 8 consecutive lanes of the wave that owns the row.
+__global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restrict__ x, size_t ldx,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int rows, int D, float eps, uint8_t* __restrict__ q, size_t ldq,
+                                                           uint8_t* __restrict__ sc, long long rows_pad,
+                                                           const int32_t* __restrict__ count_dev, int rows_per_count) {
+    if (count_dev) {
+        long long r = (long long)count_dev[0] * rows_per_count;
+        rows = r < rows ? (int)r : rows;
+    }
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    const int nch = D >> 2;
+    float4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nch) {
+            v[i] = ((const float4*)xr)[c];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            qq += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= nch) continue;                                   // D is a multiple of 128: whole 8-lane groups drop out
+        const float4 g = ((const float4*)gamma)[c], b = ((const float4*)beta)[c];
+        // the bf16 rounding of the unfused path is kept, so both paths quantise the same numbers
+        const float o0 = bf16_to_f32(f32_to_bf16((v[i].x - mean) * rstd * g.x + b.x));
+        const float o1 = bf16_to_f32(f32_to_bf16((v[i].y - mean) * rstd * g.y + b.y));
+        const float o2 = bf16_to_f32(f32_to_bf16((v[i].z - mean) * rstd * g.z + b.z));
+        const float o3 = bf16_to_f32(f32_to_bf16((v[i].w - mean) * rstd * g.w + b.w));
+        float amax = fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3)));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        int e = -127;
+        if (amax > 0.f) {
+            int ex;
+            const float mant = frexpf(amax * (1.0f / 448.0f), &ex);
+            e = mant == 0.5f ? ex - 1 : ex;
+            e = e < -127 ? -127 : (e > 127 ? 127 : e);
+        }
+        const float inv = ldexpf(1.0f, -e);
+        int p = 0;
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(o0 * inv, o1 * inv, p, false);
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(o2 * inv, o3 * inv, p, true);
+        *(uint32_t*)(q + (size_t)row * ldq + 4 * c) = (uint32_t)p;
+        if ((lane & 7) == 0) {
+            const int bk = c >> 3;
+            sc[((long long)(bk >> 2) * rows_pad + row) * 4 + (bk & 3)] = (uint8_t)(e + 127);
+        }
+    }
+}
+
 __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, int R, int tok, int D,
                                 float* __restrict__ x) {
     const int r = blockIdx.x;
@@ -130,6 +201,18 @@ extern "C" int yv_layernorm(const float* x, size_t ldx, const float* gamma, cons
     if (rows == 0) return YV_OK;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
                        rows, D, eps, (uint16_t*)y, ldy, count_dev, rows_per_count);
+    return yv_launch_status();
+}
+
+extern "C" int yv_layernorm_mxfp8(const float* x, size_t ldx, const float* gamma, const float* beta, int rows, int D, float eps,
+                                  void* q, size_t ldq, void* scales, long long rows_pad, const int32_t* count_dev,
+                                  int rows_per_count, void* stream) {
+    if (!x || !gamma || !beta || !q || !scales || rows < 0 || D <= 0) return YV_ERR_ARG;
+    if ((D & 127) || (ldx & 3) || (ldq & 15) || rows_pad < rows || (rows_pad & 127)) return YV_ERR_ARG;
+    if (D > LN_MAXC * 256) return YV_ERR_LIMIT;
+    if (rows == 0) return YV_OK;
+    hipLaunchKernelGGL(layernorm_mx_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, rows, D,
+                       eps, (uint8_t*)q, ldq, (uint8_t*)scales, rows_pad, count_dev, rows_per_count);
     return yv_launch_status();
 }
 

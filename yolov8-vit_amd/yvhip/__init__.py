@@ -54,6 +54,7 @@ _SIGS = {
     "yv_set_option": (_i, [C.c_char_p, _i]),
     "yv_set_workspace": (_i, [_vp, _vp, _sz]),
     "yv_set_launch_timing": (_i, [_vp, _vp]),
+    "yv_layernorm_mxfp8": (_i, [_vp, _sz, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, C.c_longlong, _vp, _i, _vp]),
     "yv_mx_probe": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "yv_quant_mxfp8": (_i, [_vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, _vp, C.c_longlong, _vp]),
     "yv_linear_mxfp8": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, _vp, _vp, C.c_longlong, _vp, _i, _i, _i, _vp, _i, _i, _vp,
@@ -708,3 +709,10 @@ def linear_mxfp8(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_sc
     check(lib.yv_linear_mxfp8(_p(aq), aq.stride(0), _p(a_scale), a_scale.shape[1], _p(wq), _p(w_scale), w_scale.shape[1],
                               _p(bias), M, N, K, _p(out), out.stride(0), flags, _p(m_dev), m_mul, _st()), "yv_linear_mxfp8")
     return out
+
+
+def layernorm_mxfp8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, q: torch.Tensor, scales: torch.Tensor, rows: int,
+                    D: int, ldx: int, eps: float = 1e-6, count_dev: Optional[torch.Tensor] = None, rows_per_count: int = 1):
+    """LayerNorm -> MXFP8 operand (q (rows, D) e4m3 bytes, scales (D/128, rows_pad, 4) E8M0) in one pass."""
+    check(lib.yv_layernorm_mxfp8(_p(x), ldx, _p(gamma), _p(beta), rows, D, float(eps), _p(q), q.stride(0), _p(scales),
+                                 scales.shape[1], _p(count_dev), rows_per_count, _st()), "yv_layernorm_mxfp8")

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import (EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, cls_rows,
-               conv2d, detect_decode, layernorm, linear, linear_mxfp8, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
+               conv2d, detect_decode, layernorm, layernorm_mxfp8, linear, linear_mxfp8, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
                wrapper_head)
 
 # --------------------------------------------------------------------------------------- YOLOv8
@@ -414,13 +414,15 @@ class VitEngine:
             quant_mxfp8(src, aq, asc)
             linear_mxfp8(aq, asc, wq, ws, bias, out, flags=flags, m_dev=count, m_mul=N)
 
+        hq = b["q"].view(-1)[:rows * D].view(rows, D)                       # LayerNorm writes the MXFP8 operand directly
+        hs = b["qs"].view(-1)[:(D // 128) * rp * 4].view(D // 128, rp, 4)
         for blk in self.blocks:
-            layernorm(x, blk["n1w"], blk["n1b"], h, rows, D, D, D, count_dev=count, rows_per_count=N)
-            gemm(h, D, blk["wqkv_q"], blk["wqkv_s"], blk["bqkv"], qkv, 0)
+            layernorm_mxfp8(x, blk["n1w"], blk["n1b"], hq, hs, rows, D, D, count_dev=count, rows_per_count=N)
+            linear_mxfp8(hq, hs, blk["wqkv_q"], blk["wqkv_s"], blk["bqkv"], qkv, m_dev=count, m_mul=N)
             attention(qkv, cap, N, H, o, r_dev=count)
             gemm(o, D, blk["wproj_q"], blk["wproj_s"], blk["bproj"], x, EPI_RES_F32)
-            layernorm(x, blk["n2w"], blk["n2b"], h, rows, D, D, D, count_dev=count, rows_per_count=N)
-            gemm(h, D, blk["wfc1_q"], blk["wfc1_s"], blk["bfc1"], gbuf, EPI_GELU)
+            layernorm_mxfp8(x, blk["n2w"], blk["n2b"], hq, hs, rows, D, D, count_dev=count, rows_per_count=N)
+            linear_mxfp8(hq, hs, blk["wfc1_q"], blk["wfc1_s"], blk["bfc1"], gbuf, flags=EPI_GELU, m_dev=count, m_mul=N)
             gemm(gbuf, 4 * D, blk["wfc2_q"], blk["wfc2_s"], blk["bfc2"], x, EPI_RES_F32)
         layernorm(x, self.nw, self.nb, b["c"], cap, D, N * D, D, count_dev=count, rows_per_count=1)
         linear(b["c"], self.w_head, self.b_head, b["feats"], flags=EPI_OUT_F32, m_dev=count, m_mul=1)
