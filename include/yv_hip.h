@@ -50,6 +50,12 @@ int yv_set_option(const char* key, int value);
  *   e = ceil(log2(amax/448)) per block, q = RNE_e4m3(x * 2^-e); K a multiple of 128.
  * yv_linear_mxfp8: out[M,N] = (Aq*2^sa)[M,K] . (Wq*2^sw)[N,K]^T with the epilogues of yv_linear (bias, GELU, f32 residual
  *   read-modify-write, f32 output). */
+/* yv_linear_mxfp8 whose OUTPUT is again an MXFP8 operand (bias / GELU applied, rounded to bf16, then quantised in the
+ * epilogue): the fc1 -> fc2 hand-off of the MLP without a bf16 round trip through HBM.  N a multiple of 128. */
+int yv_linear_mxfp8_q(const void* Aq, long long lda, const void* Ascale, long long a_rows_pad, const void* Wq, const void* Wscale,
+                      long long w_rows_pad, const float* bias, int M, int N, int K, int flags, const int32_t* m_dev, int m_mul,
+                      void* out_q, long long ldq, void* out_scales, long long out_rows_pad, void* stream);
+
 /* yv_layernorm with the output written directly in the MXFP8 operand format (same numbers as yv_layernorm followed by
  * yv_quant_mxfp8: the bf16 rounding is kept); D a multiple of 128. */
 int yv_layernorm_mxfp8(const float* x, size_t ldx, const float* gamma, const float* beta, int rows, int D, float eps, void* q,
@@ -162,6 +168,7 @@ typedef struct yv_view {
 #define YV_EPI_POSEMB 64    /* patch-embed row remap + pos_embed add          */
 #define YV_EPI_SAVE_PRE 128 /* also store the pre-activation (bf16) to `aux`   */
 #define YV_EPI_GELU_BWD 256 /* out = acc * gelu'(aux)  (MLP backward)         */
+#define YV_EPI_OUT_MXFP8 512 /* internal to yv_linear_mxfp8_q: e4m3 + E8M0 output */
 
 /* Conv2d(k in {1,3}, stride in {1,2}, pad k/2) + folded-BN bias + SiLU as an
  * implicit GEMM on MFMA (ultralytics Conv/C2f/SPPF/Detect convs; structure per

@@ -161,3 +161,25 @@ def test_layernorm_mxfp8_equals_layernorm_then_quant(yv):
     torch.cuda.synchronize()
     assert torch.equal(q[:300], q_ref[:300]) and torch.equal(s[:, :300], s_ref[:, :300])
     assert float(q[300:].float().abs().sum()) == 0                              # rows past the count stay untouched
+
+
+def test_linear_mxfp8_q_equals_linear_then_quant(yv):
+    """fc1 -> fc2 hand-off: the GEMM epilogue that emits MXFP8 directly must equal the bf16-output GEMM followed by
+    yv_quant_mxfp8, byte for byte (ragged M, device-side row count)."""
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 330, 512, 256
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    aq, asc = yv.quant_mxfp8(a)
+    wq, wsc = yv.quant_mxfp8(w)
+    cnt = torch.tensor([3], dtype=torch.int32, device=DEV)                      # 3 x 100 live rows
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    yv.linear_mxfp8(aq, asc, wq, wsc, bias, out, flags=yv.EPI_GELU, m_dev=cnt, m_mul=100)
+    q_ref, s_ref = yv.quant_mxfp8(out)
+    q = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+    s = torch.zeros_like(s_ref)
+    yv.linear_mxfp8_q(aq, asc, wq, wsc, bias, q, s, flags=yv.EPI_GELU, m_dev=cnt, m_mul=100)
+    torch.cuda.synchronize()
+    assert torch.equal(q[:300], q_ref[:300]) and torch.equal(s[:, :300], s_ref[:, :300])
+    assert float(q[300:].float().abs().sum()) == 0

@@ -79,6 +79,10 @@ struct GemmArgs {
     int splitk;                  // conv only: K range split over `splitk` workgroups per tile (partials in `partial`)
     float* partial;              // (splitk, M, N) f32
     int staged;                  // coalesced LDS-staged epilogue usable (alignment / width checked on the host)
+    uint8_t* mxq;                // YV_EPI_OUT_MXFP8: e4m3 image of the output (row stride ldmxq bytes) ...
+    long long ldmxq;
+    uint8_t* mxs;                // ... and its E8M0 block scales, K-step-major (N/128, mx_rows, 4)
+    long long mx_rows;
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
@@ -241,6 +245,38 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x4 (&acc)[
                         o[q] = pack_bf16x2(bf16_to_f32((uint16_t)(a[q] & 0xffff)) + bf16_to_f32((uint16_t)(b[q] & 0xffff)),
                                            bf16_to_f32((uint16_t)(a[q] >> 16)) + bf16_to_f32((uint16_t)(b[q] >> 16)));
                     pk = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+                if (flags & YV_EPI_OUT_MXFP8) {
+                    // the consumer is another MXFP8 GEMM: quantise the 8 (bf16-rounded) values of this lane together with
+                    // the 3 lanes that hold the rest of their 32-column block, skip the bf16 store
+                    const uint32_t a[4] = {pk.x, pk.y, pk.z, pk.w};
+                    float f[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { f[2 * q] = bf16_to_f32((uint16_t)(a[q] & 0xffff)); f[2 * q + 1] = bf16_to_f32((uint16_t)(a[q] >> 16)); }
+                    float amax = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) amax = fmaxf(amax, fabsf(f[q]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                    int e = -127;
+                    if (amax > 0.f) {
+                        int ex;
+                        const float mant = frexpf(amax * (1.0f / 448.0f), &ex);
+                        e = mant == 0.5f ? ex - 1 : ex;
+                        e = e < -127 ? -127 : (e > 127 ? 127 : e);
+                    }
+                    const float inv = ldexpf(1.0f, -e);
+                    int p0 = 0, p1 = 0;
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, p0, false);
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, p0, true);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, p1, false);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, p1, true);
+                    *(uint2*)(g.mxq + (long long)m * g.ldmxq + n) = make_uint2((uint32_t)p0, (uint32_t)p1);
+                    if ((ch & 3) == 0) {
+                        const int bk = n >> 5;
+                        g.mxs[((long long)(bk >> 2) * g.mx_rows + m) * 4 + (bk & 3)] = (uint8_t)(e + 127);
+                    }
+                    continue;
                 }
                 if (flags & YV_EPI_GELU_BWD) {      // out = dg * gelu'(u), u = saved pre-activation (bf16)
                     const uint4 uu = *(const uint4*)(g.aux + (long long)m * g.ldaux + n);
@@ -1219,15 +1255,39 @@ extern "C" int yv_quant_mxfp8(const void* x, long long ldx, long long rows, int 
     return yv_launch_status();
 }
 
+static int linear_mx_impl(const void* Aq, long long lda, const void* Ascale, long long a_rows_pad, const void* Wq,
+                          const void* Wscale, long long w_rows_pad, const float* bias, int M, int N, int K, void* out,
+                          int ldo, int flags, const int32_t* m_dev, int m_mul, void* out_q, long long ldq, void* out_scales,
+                          long long out_rows_pad, void* stream);
+
 extern "C" int yv_linear_mxfp8(const void* Aq, long long lda, const void* Ascale, long long a_rows_pad, const void* Wq,
                                const void* Wscale, long long w_rows_pad, const float* bias, int M, int N, int K, void* out,
                                int ldo, int flags, const int32_t* m_dev, int m_mul, void* stream) {
+    if (flags & YV_EPI_OUT_MXFP8) return YV_ERR_ARG;
+    return linear_mx_impl(Aq, lda, Ascale, a_rows_pad, Wq, Wscale, w_rows_pad, bias, M, N, K, out, ldo, flags, m_dev, m_mul,
+                          nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int yv_linear_mxfp8_q(const void* Aq, long long lda, const void* Ascale, long long a_rows_pad, const void* Wq,
+                                 const void* Wscale, long long w_rows_pad, const float* bias, int M, int N, int K, int flags,
+                                 const int32_t* m_dev, int m_mul, void* out_q, long long ldq, void* out_scales,
+                                 long long out_rows_pad, void* stream) {
+    if (!out_q || !out_scales || (N & 127) || (ldq & 15) || ldq < N || out_rows_pad < M || (out_rows_pad & 127)) return YV_ERR_ARG;
+    if (flags & ~(YV_EPI_BIAS | YV_EPI_GELU)) return YV_ERR_ARG;
+    return linear_mx_impl(Aq, lda, Ascale, a_rows_pad, Wq, Wscale, w_rows_pad, bias, M, N, K, out_q, (int)ldq,
+                          flags | YV_EPI_OUT_MXFP8, m_dev, m_mul, out_q, ldq, out_scales, out_rows_pad, stream);
+}
+
+static int linear_mx_impl(const void* Aq, long long lda, const void* Ascale, long long a_rows_pad, const void* Wq,
+                          const void* Wscale, long long w_rows_pad, const float* bias, int M, int N, int K, void* out,
+                          int ldo, int flags, const int32_t* m_dev, int m_mul, void* out_q, long long ldq, void* out_scales,
+                          long long out_rows_pad, void* stream) {
     if (!Aq || !Ascale || !Wq || !Wscale || !out || M < 0 || N <= 0 || K <= 0) return YV_ERR_ARG;
     if ((K & 127) || (lda & 15) || (N & 7) || (ldo & 7)) return YV_ERR_ARG;             // whole 128-element K steps
     if (a_rows_pad < M || (a_rows_pad & 127) || w_rows_pad < N || (w_rows_pad & 127)) return YV_ERR_ARG;
     if (((uintptr_t)Ascale | (uintptr_t)Wscale) & 15) return YV_ERR_ARG;
     if ((flags & YV_EPI_BIAS) && !bias) return YV_ERR_ARG;
-    if (flags & ~(YV_EPI_BIAS | YV_EPI_GELU | YV_EPI_RES_F32 | YV_EPI_OUT_F32)) return YV_ERR_ARG;
+    if (flags & ~(YV_EPI_BIAS | YV_EPI_GELU | YV_EPI_RES_F32 | YV_EPI_OUT_F32 | YV_EPI_OUT_MXFP8)) return YV_ERR_ARG;
     if (((uintptr_t)Aq | (uintptr_t)Wq | (uintptr_t)out) & 15) return YV_ERR_ARG;
     if (M == 0) return YV_OK;
     MxArgs a = {};
@@ -1240,6 +1300,7 @@ extern "C" int yv_linear_mxfp8(const void* Aq, long long lda, const void* Ascale
     g.group_m = g_opt_group_m > 0 ? g_opt_group_m : 8;
     g.tiles_m = (M + 127) / 128; g.tiles_n = (N + 127) / 128;
     a.sa = (const uint8_t*)Ascale; a.sw = (const uint8_t*)Wscale; a.rows_a = a_rows_pad; a.rows_w = w_rows_pad;
+    g.mxq = (uint8_t*)out_q; g.ldmxq = ldq; g.mxs = (uint8_t*)out_scales; g.mx_rows = out_rows_pad;
     const size_t lds = 2 * (size_t)(128 * 128 * 2 + 1024);
     if (hipFuncSetAttribute((const void*)gemm_mx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;

@@ -54,6 +54,8 @@ _SIGS = {
     "yv_set_option": (_i, [C.c_char_p, _i]),
     "yv_set_workspace": (_i, [_vp, _vp, _sz]),
     "yv_set_launch_timing": (_i, [_vp, _vp]),
+    "yv_linear_mxfp8_q": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, _vp, _vp, C.c_longlong, _vp, _i, _i, _i, _i, _vp, _i, _vp,
+                               C.c_longlong, _vp, C.c_longlong, _vp]),
     "yv_layernorm_mxfp8": (_i, [_vp, _sz, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, C.c_longlong, _vp, _i, _vp]),
     "yv_mx_probe": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "yv_quant_mxfp8": (_i, [_vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, _vp, C.c_longlong, _vp]),
@@ -716,3 +718,17 @@ def layernorm_mxfp8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, q:
     """LayerNorm -> MXFP8 operand (q (rows, D) e4m3 bytes, scales (D/128, rows_pad, 4) E8M0) in one pass."""
     check(lib.yv_layernorm_mxfp8(_p(x), ldx, _p(gamma), _p(beta), rows, D, float(eps), _p(q), q.stride(0), _p(scales),
                                  scales.shape[1], _p(count_dev), rows_per_count, _st()), "yv_layernorm_mxfp8")
+
+
+def linear_mxfp8_q(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
+                   bias: Optional[torch.Tensor], out_q: torch.Tensor, out_scale: torch.Tensor, flags: int = 0,
+                   m_dev: Optional[torch.Tensor] = None, m_mul: int = 1):
+    """MXFP8 linear whose output is again an MXFP8 operand (bias / GELU -> bf16 rounding -> e4m3 + E8M0)."""
+    _chk_dev(aq, a_scale, wq, w_scale, bias, out_q, out_scale, m_dev)
+    M, K = aq.shape
+    N = wq.shape[0]
+    if bias is not None:
+        flags |= EPI_BIAS
+    check(lib.yv_linear_mxfp8_q(_p(aq), aq.stride(0), _p(a_scale), a_scale.shape[1], _p(wq), _p(w_scale), w_scale.shape[1],
+                                _p(bias), M, N, K, flags, _p(m_dev), m_mul, _p(out_q), out_q.stride(0), _p(out_scale),
+                                out_scale.shape[1], _st()), "yv_linear_mxfp8_q")

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import (EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, cls_rows,
-               conv2d, detect_decode, layernorm, layernorm_mxfp8, linear, linear_mxfp8, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
+               conv2d, detect_decode, layernorm, layernorm_mxfp8, linear, linear_mxfp8, linear_mxfp8_q, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
                wrapper_head)
 
 # --------------------------------------------------------------------------------------- YOLOv8
@@ -367,9 +367,10 @@ class VitEngine:
                 x=z((cap * N, D), torch.float32), h=z((cap * N, D), torch.bfloat16),
                 qkv=z((cap * N, 3 * D), torch.bfloat16), o=z((cap * N, D), torch.bfloat16),
                 g=z((cap * N, 4 * D), torch.bfloat16), c=z((cap, D), torch.bfloat16),
-                **({} if self.dtype != "mxfp8" else dict(
-                    q=z((cap * N, 4 * D), torch.uint8),                  # e4m3 image of the current GEMM input
-                    qs=z((4 * D // 128, (cap * N + 127) // 128 * 128, 4), torch.uint8))),
+                **({} if self.dtype != "mxfp8" else dict(          # MXFP8 operand images: bytes + K-step-major block scales
+                    q=z((cap * N, D), torch.uint8), qs=z((D // 128, (cap * N + 127) // 128 * 128, 4), torch.uint8),
+                    gq=z((cap * N, 4 * D), torch.uint8),
+                    gs=z((4 * D // 128, (cap * N + 127) // 128 * 128, 4), torch.uint8))),
                 feats=z((cap, 1024), torch.float32))
         return self._bufs[key]
 
@@ -403,27 +404,22 @@ class VitEngine:
         return b["feats"]
 
     def _backbone_mxfp8(self, b: dict, cap: int, count: Optional[torch.Tensor]) -> torch.Tensor:
+        """Block linears in MXFP8.  Operand hand-offs: LayerNorm writes the qkv / fc1 operand directly, the fc1 epilogue
+        writes the fc2 operand directly (GELU output never exists in bf16 in HBM); only the attention output is quantised
+        by a separate pass."""
         D, N, H = self.D, self.N, self.H
-        x, h, qkv, o, gbuf = b["x"], b["h"], b["qkv"], b["o"], b["g"]
+        x, qkv, o = b["x"], b["qkv"], b["o"]
+        hq, hs, gq, gs = b["q"], b["qs"], b["gq"], b["gs"]
         rows = cap * N
-        rp = b["qs"].shape[1]
-
-        def gemm(src, K, wq, ws, bias, out, flags):
-            aq = b["q"].view(-1)[:rows * K].view(rows, K)
-            asc = b["qs"].view(-1)[:(K // 128) * rp * 4].view(K // 128, rp, 4)
-            quant_mxfp8(src, aq, asc)
-            linear_mxfp8(aq, asc, wq, ws, bias, out, flags=flags, m_dev=count, m_mul=N)
-
-        hq = b["q"].view(-1)[:rows * D].view(rows, D)                       # LayerNorm writes the MXFP8 operand directly
-        hs = b["qs"].view(-1)[:(D // 128) * rp * 4].view(D // 128, rp, 4)
         for blk in self.blocks:
             layernorm_mxfp8(x, blk["n1w"], blk["n1b"], hq, hs, rows, D, D, count_dev=count, rows_per_count=N)
             linear_mxfp8(hq, hs, blk["wqkv_q"], blk["wqkv_s"], blk["bqkv"], qkv, m_dev=count, m_mul=N)
             attention(qkv, cap, N, H, o, r_dev=count)
-            gemm(o, D, blk["wproj_q"], blk["wproj_s"], blk["bproj"], x, EPI_RES_F32)
+            quant_mxfp8(o, hq, hs)
+            linear_mxfp8(hq, hs, blk["wproj_q"], blk["wproj_s"], blk["bproj"], x, flags=EPI_RES_F32, m_dev=count, m_mul=N)
             layernorm_mxfp8(x, blk["n2w"], blk["n2b"], hq, hs, rows, D, D, count_dev=count, rows_per_count=N)
-            linear_mxfp8(hq, hs, blk["wfc1_q"], blk["wfc1_s"], blk["bfc1"], gbuf, flags=EPI_GELU, m_dev=count, m_mul=N)
-            gemm(gbuf, 4 * D, blk["wfc2_q"], blk["wfc2_s"], blk["bfc2"], x, EPI_RES_F32)
+            linear_mxfp8_q(hq, hs, blk["wfc1_q"], blk["wfc1_s"], blk["bfc1"], gq, gs, flags=EPI_GELU, m_dev=count, m_mul=N)
+            linear_mxfp8(gq, gs, blk["wfc2_q"], blk["wfc2_s"], blk["bfc2"], x, flags=EPI_RES_F32, m_dev=count, m_mul=N)
         layernorm(x, self.nw, self.nb, b["c"], cap, D, N * D, D, count_dev=count, rows_per_count=1)
         linear(b["c"], self.w_head, self.b_head, b["feats"], flags=EPI_OUT_F32, m_dev=count, m_mul=1)
         return b["feats"]
