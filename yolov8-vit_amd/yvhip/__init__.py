@@ -689,10 +689,10 @@ def axpby(dst: torch.Tensor, src: torch.Tensor, a: float, b: float):
 
 # ------------------------------------------------------------- MXFP8 linears (BASELINE configs[4])
 def quant_mxfp8(x: torch.Tensor, q: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None):
-    """x (rows, K) bf16 -> (q (rows, K) uint8 e4m3 bytes, scales (K/128, rows_pad, 4) uint8 E8M0, rows_pad = rows up to 128)."""
+    """x (rows, K) bf16 -> (q (rows, K) uint8 e4m3 bytes, scales (K/128, rows_pad, 4) uint8 E8M0, rows_pad = rows up to 256)."""
     _chk_dev(x, q, scales)
     rows, K = x.shape
-    rp = (rows + 127) // 128 * 128
+    rp = (rows + 255) // 256 * 256
     q = torch.empty((rows, K), dtype=torch.uint8, device=x.device) if q is None else q
     scales = torch.zeros((K // 128, rp, 4), dtype=torch.uint8, device=x.device) if scales is None else scales
     check(lib.yv_quant_mxfp8(_p(x), x.stride(0), rows, K, _p(q), q.stride(0), _p(scales), scales.shape[1], _st()),

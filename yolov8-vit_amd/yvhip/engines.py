@@ -368,9 +368,9 @@ class VitEngine:
                 qkv=z((cap * N, 3 * D), torch.bfloat16), o=z((cap * N, D), torch.bfloat16),
                 g=z((cap * N, 4 * D), torch.bfloat16), c=z((cap, D), torch.bfloat16),
                 **({} if self.dtype != "mxfp8" else dict(          # MXFP8 operand images: bytes + K-step-major block scales
-                    q=z((cap * N, D), torch.uint8), qs=z((D // 128, (cap * N + 127) // 128 * 128, 4), torch.uint8),
+                    q=z((cap * N, D), torch.uint8), qs=z((D // 128, (cap * N + 255) // 256 * 256, 4), torch.uint8),
                     gq=z((cap * N, 4 * D), torch.uint8),
-                    gs=z((4 * D // 128, (cap * N + 127) // 128 * 128, 4), torch.uint8))),
+                    gs=z((4 * D // 128, (cap * N + 255) // 256 * 256, 4), torch.uint8))),
                 feats=z((cap, 1024), torch.float32))
         return self._bufs[key]
 
