@@ -261,7 +261,9 @@ def main():
             "config": {"workload": ("YOLOv8m(nc=5)+ViT-L/16 end-to-end inference, 640x640 (model pair of BASELINE.json "
                                     "configs[4]); classifier block linears in " + args.dtype) if large else
                                    ("YOLOv8n(nc=5)+ViT-B/16 end-to-end inference, 640x640, bf16 "
-                                    "(BASELINE.json configs[1])"), "batch_per_gpu": B, "global_batch": B * world,
+                                    "(BASELINE.json configs[1])" if args.dtype == "bf16" else
+                                    "YOLOv8n(nc=5)+ViT-B/16 end-to-end inference, 640x640, classifier block linears in "
+                                    "mxfp8 (NOT the headline configuration, which is bf16)"), "batch_per_gpu": B, "global_batch": B * world,
                        "crops_per_image": R, "crops_per_step_rank0": crops_step, "parallelism": f"dp{world}",
                        "schedule": "single stream" if runner is None else
                                    ("HIP streams: detector of batch i+1 (high priority) overlaps classifier of batch i" +
