@@ -183,3 +183,30 @@ def test_linear_mxfp8_q_equals_linear_then_quant(yv):
     torch.cuda.synchronize()
     assert torch.equal(q[:300], q_ref[:300]) and torch.equal(s[:, :300], s_ref[:, :300])
     assert float(q[300:].float().abs().sum()) == 0
+
+
+def test_pipeline_with_mxfp8_classifier(yv):
+    """The whole detect -> crop -> classify pipeline with an MXFP8 classifier: the pipelined two-stream / split schedule
+    gives bitwise the single-stream results (per-slot operand buffers, device-side crop count)."""
+    from yvhip import engines
+    from yvhip.pipeline import DetectClassifyPipeline, PipelinedRunner
+    name, S, B = "vit_tiny_test", 128, 4
+    vit = engines.VitEngine(engines.init_vit_wrapper_state(name, 5, 4), name, 5, device=DEV, dtype="mxfp8")
+    pipe = DetectClassifyPipeline(engines.YoloEngine(engines.init_yolo_state("n", 5, 3, 4.0), "n", 5, S, DEV), [vit],
+                                  max_crops_per_image=3)
+    g = torch.Generator().manual_seed(41)
+    batches = [torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).to(DEV) for _ in range(4)]
+    keys = ("crop_list", "crop_total", "cls_logits", "cls_label")
+    ref = []
+    for im in batches:
+        o = pipe(im)
+        torch.cuda.synchronize()
+        ref.append({k: o[k].clone() for k in keys})
+    assert any(int(r["crop_total"][0]) > 0 for r in ref)
+    for split in (False, True):
+        runner = PipelinedRunner(pipe, split_classifier=split)
+        outs = [runner.submit(im) for im in batches]
+        runner.sync()
+        for o, r in zip(outs, ref):
+            for k in keys:
+                assert torch.equal(o[k], r[k]), (split, k)
