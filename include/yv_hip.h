@@ -56,6 +56,11 @@ int yv_linear_mxfp8_q(const void* Aq, long long lda, const void* Ascale, long lo
                       long long w_rows_pad, const float* bias, int M, int N, int K, int flags, const int32_t* m_dev, int m_mul,
                       void* out_q, long long ldq, void* out_scales, long long out_rows_pad, void* stream);
 
+/* yv_attention with the output written directly in the MXFP8 operand format of the proj GEMM (same numbers as
+ * yv_attention followed by yv_quant_mxfp8); H even. */
+int yv_attention_mxfp8(const void* qkv, int R, int N, int H, float scale, void* out_q, long long ldq, void* out_scales,
+                       long long rows_pad, const int32_t* r_dev, void* stream);
+
 /* yv_layernorm with the output written directly in the MXFP8 operand format (same numbers as yv_layernorm followed by
  * yv_quant_mxfp8: the bf16 rounding is kept); D a multiple of 128. */
 int yv_layernorm_mxfp8(const float* x, size_t ldx, const float* gamma, const float* beta, int rows, int D, float eps, void* q,

@@ -210,3 +210,23 @@ def test_pipeline_with_mxfp8_classifier(yv):
         for o, r in zip(outs, ref):
             for k in keys:
                 assert torch.equal(o[k], r[k]), (split, k)
+
+
+@pytest.mark.parametrize("R,N,H", [(3, 197, 12), (2, 50, 2), (1, 785, 4)])
+def test_attention_mxfp8_equals_attention_then_quant(yv, R, N, H):
+    """Attention whose epilogue emits the MXFP8 operand of the proj GEMM: identical bytes and scales to yv_attention
+    followed by yv_quant_mxfp8 (single-tile and online-softmax kernels, device-side crop count)."""
+    g = torch.Generator().manual_seed(R * 1000 + N + H)
+    D = H * 64
+    qkv = (torch.randn(R * N, 3 * D, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+    cnt = torch.tensor([max(R - 1, 1)], dtype=torch.int32, device=DEV)
+    live = int(cnt[0]) * N
+    o = torch.zeros(R * N, D, dtype=torch.bfloat16, device=DEV)
+    yv.attention(qkv, R, N, H, o, r_dev=cnt)
+    q_ref, s_ref = yv.quant_mxfp8(o)
+    q = torch.zeros(R * N, D, dtype=torch.uint8, device=DEV)
+    s = torch.zeros_like(s_ref)
+    yv.attention_mxfp8(qkv, R, N, H, q, s, r_dev=cnt)
+    torch.cuda.synchronize()
+    assert torch.equal(q[:live], q_ref[:live]) and torch.equal(s[:, :live], s_ref[:, :live])
+    assert float(q[live:].float().abs().sum()) == 0

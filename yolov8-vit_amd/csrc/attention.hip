@@ -25,10 +25,13 @@ namespace {
 constexpr int HD = 64;
 int g_attn_abl = 0;               // diagnostic builds (yv_attention_debug)
 
+// optional MXFP8 image of the output (operand of the proj GEMM of yv_linear_mxfp8): e4m3 bytes + E8M0 per 32 columns
+struct AttnMx { uint8_t* q; long long ldq; uint8_t* s; long long rows; };
+
 template <int NT, int ABL = 0>
 __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __restrict__ qkv, int N, int H, int QB,
                                                             float scale_log2e, uint16_t* __restrict__ out,
-                                                            const int32_t* __restrict__ r_dev, float* __restrict__ lse) {
+                                                            const int32_t* __restrict__ r_dev, float* __restrict__ lse, AttnMx mx) {
     // blockIdx.x = ((crop * H + head) * QB + query block); a query block = NT waves x 32 queries = NP rows.
     // Keys/values are consumed in tiles of NP rows with an online softmax (running max m, sum l, rescaled
     // O); N <= NP (ViT-x/16: 197 <= 224) is the single-tile case and pays no rescale.
@@ -164,6 +167,38 @@ __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __re
     if (q < N) {
         if (lse && hh == 0) lse[((size_t)r * H + hd) * N + q] = m_run * scale_log2e + log2f(l_run);   // log2 domain
         const float inv = 1.0f / l_run;
+        if (mx.q) {
+            // a head's 64 columns are two MX blocks (d 0..31 = mt 0, d 32..63 = mt 1); a query's values of one block sit
+            // in this lane and in lane ^ 32; the bf16 rounding of the ordinary output is kept
+            const long long row = (long long)r * N + q;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float f[16], amax = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { f[k] = bf16_to_f32(f32_to_bf16(o[mt][k] * inv)); amax = fmaxf(amax, fabsf(f[k])); }
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                int e = -127;
+                if (amax > 0.f) {
+                    int ex;
+                    const float mant = frexpf(amax * (1.0f / 448.0f), &ex);
+                    e = mant == 0.5f ? ex - 1 : ex;
+                    e = e < -127 ? -127 : (e > 127 ? 127 : e);
+                }
+                const float is = ldexpf(1.0f, -e);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    int p = 0;
+                    p = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * g4] * is, f[4 * g4 + 1] * is, p, false);
+                    p = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * g4 + 2] * is, f[4 * g4 + 3] * is, p, true);
+                    *(uint32_t*)(mx.q + row * mx.ldq + hd * HD + mt * 32 + 8 * g4 + 4 * hh) = (uint32_t)p;
+                }
+                if (hh == 0) {
+                    const int bk = hd * 2 + mt;
+                    mx.s[((long long)(bk >> 2) * mx.rows + row) * 4 + (bk & 3)] = (uint8_t)(e + 127);
+                }
+            }
+            return;
+        }
         uint16_t* orow = out + ((size_t)r * N + q) * D + hd * HD;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -178,7 +213,7 @@ __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __re
 
 template <int NT>
 int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t* out, const int32_t* r_dev, float* lse,
-                hipStream_t st) {
+                hipStream_t st, AttnMx mx) {
     constexpr int NP = NT * 32;
     const size_t lds = (size_t)NP * 128 + 64 * (size_t)(NP * 2 + 8);
     auto kern = g_attn_abl == 1 ? attention_kernel<NT, 1> : g_attn_abl == 2 ? attention_kernel<NT, 2> : g_attn_abl == 3 ? attention_kernel<NT, 3> : attention_kernel<NT, 0>;
@@ -187,15 +222,15 @@ int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t*
         return YV_ERR_LAUNCH;
     const int QB = (N + NP - 1) / NP;
     hipLaunchKernelGGL(kern, dim3(R * H * QB), dim3(NT * 64), lds, st, qkv, N, H, QB, scale * 1.4426950408889634f, out,
-                       r_dev, lse);
+                       r_dev, lse, mx);
     return yv_launch_status();
 }
 
 }  // namespace
 
 static int attention_impl(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev, float* lse,
-                          void* stream) {
-    if (!qkv || !out || R < 0 || N <= 0 || H <= 0) return YV_ERR_ARG;
+                          void* stream, AttnMx mx = AttnMx{nullptr, 0, nullptr, 0}) {
+    if (!qkv || (!out && !mx.q) || R < 0 || N <= 0 || H <= 0) return YV_ERR_ARG;
     if ((long long)R * H * ((N + 255) / 256) > 0x7fffffffLL) return YV_ERR_LIMIT;
     if (R == 0) return YV_OK;
     const uint16_t* q = (const uint16_t*)qkv;
@@ -203,14 +238,14 @@ static int attention_impl(const void* qkv, int R, int N, int H, float scale, voi
     hipStream_t st = (hipStream_t)stream;
     const int nt = N > 256 ? 8 : (N + 31) / 32;        // > 256 tokens: 256-row tiles, online softmax
     switch (nt) {
-        case 1: return launch_attn<1>(q, R, N, H, scale, o, r_dev, lse, st);
-        case 2: return launch_attn<2>(q, R, N, H, scale, o, r_dev, lse, st);
-        case 3: return launch_attn<3>(q, R, N, H, scale, o, r_dev, lse, st);
-        case 4: return launch_attn<4>(q, R, N, H, scale, o, r_dev, lse, st);
-        case 5: return launch_attn<5>(q, R, N, H, scale, o, r_dev, lse, st);
-        case 6: return launch_attn<6>(q, R, N, H, scale, o, r_dev, lse, st);
-        case 7: return launch_attn<7>(q, R, N, H, scale, o, r_dev, lse, st);
-        default: return launch_attn<8>(q, R, N, H, scale, o, r_dev, lse, st);
+        case 1: return launch_attn<1>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+        case 2: return launch_attn<2>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+        case 3: return launch_attn<3>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+        case 4: return launch_attn<4>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+        case 5: return launch_attn<5>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+        case 6: return launch_attn<6>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+        case 7: return launch_attn<7>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+        default: return launch_attn<8>(q, R, N, H, scale, o, r_dev, lse, st, mx);
     }
 }
 
@@ -219,6 +254,15 @@ extern "C" int yv_attention_debug(int ablate) { g_attn_abl = ablate; return YV_O
 extern "C" int yv_attention(const void* qkv, int R, int N, int H, float scale, void* out, const int32_t* r_dev,
                             void* stream) {
     return attention_impl(qkv, R, N, H, scale, out, r_dev, nullptr, stream);
+}
+
+extern "C" int yv_attention_mxfp8(const void* qkv, int R, int N, int H, float scale, void* out_q, long long ldq,
+                                  void* out_scales, long long rows_pad, const int32_t* r_dev, void* stream) {
+    if (!out_q || !out_scales || (ldq & 15) || ldq < (long long)H * 64 || rows_pad < (long long)R * N || (rows_pad & 127))
+        return YV_ERR_ARG;
+    if ((H & 1)) return YV_ERR_ARG;                         // whole 128-column K steps of the consumer: H*64 % 128 == 0
+    return attention_impl(qkv, R, N, H, scale, nullptr, r_dev, nullptr, stream,
+                          AttnMx{(uint8_t*)out_q, ldq, (uint8_t*)out_scales, rows_pad});
 }
 
 extern "C" int yv_attention_train(const void* qkv, int R, int N, int H, float scale, void* out, float* lse, void* stream) {

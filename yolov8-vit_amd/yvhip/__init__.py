@@ -56,6 +56,7 @@ _SIGS = {
     "yv_set_launch_timing": (_i, [_vp, _vp]),
     "yv_linear_mxfp8_q": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, _vp, _vp, C.c_longlong, _vp, _i, _i, _i, _i, _vp, _i, _vp,
                                C.c_longlong, _vp, C.c_longlong, _vp]),
+    "yv_attention_mxfp8": (_i, [_vp, _i, _i, _i, _f, _vp, C.c_longlong, _vp, C.c_longlong, _vp, _vp]),
     "yv_layernorm_mxfp8": (_i, [_vp, _sz, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, C.c_longlong, _vp, _i, _vp]),
     "yv_mx_probe": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "yv_quant_mxfp8": (_i, [_vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, _vp, C.c_longlong, _vp]),
@@ -732,3 +733,10 @@ def linear_mxfp8_q(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_
     check(lib.yv_linear_mxfp8_q(_p(aq), aq.stride(0), _p(a_scale), a_scale.shape[1], _p(wq), _p(w_scale), w_scale.shape[1],
                                 _p(bias), M, N, K, flags, _p(m_dev), m_mul, _p(out_q), out_q.stride(0), _p(out_scale),
                                 out_scale.shape[1], _st()), "yv_linear_mxfp8_q")
+
+
+def attention_mxfp8(qkv: torch.Tensor, R: int, N: int, H: int, out_q: torch.Tensor, out_scale: torch.Tensor,
+                    scale: Optional[float] = None, r_dev: Optional[torch.Tensor] = None):
+    _chk_dev(qkv, out_q, out_scale, r_dev)
+    check(lib.yv_attention_mxfp8(_p(qkv), R, N, H, float(64 ** -0.5 if scale is None else scale), _p(out_q), out_q.stride(0),
+                                 _p(out_scale), out_scale.shape[1], _p(r_dev), _st()), "yv_attention_mxfp8")

@@ -17,7 +17,8 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from . import (EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, cls_rows,
+from . import (EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, attention_mxfp8,
+               cls_rows,
                conv2d, detect_decode, layernorm, layernorm_mxfp8, linear, linear_mxfp8, linear_mxfp8_q, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
                wrapper_head)
 
@@ -405,8 +406,8 @@ class VitEngine:
 
     def _backbone_mxfp8(self, b: dict, cap: int, count: Optional[torch.Tensor]) -> torch.Tensor:
         """Block linears in MXFP8.  Operand hand-offs: LayerNorm writes the qkv / fc1 operand directly, the fc1 epilogue
-        writes the fc2 operand directly (GELU output never exists in bf16 in HBM); only the attention output is quantised
-        by a separate pass."""
+        writes the fc2 operand directly (GELU output never exists in bf16 in HBM), attention writes the proj operand
+        directly: no separate quantisation pass is left."""
         D, N, H = self.D, self.N, self.H
         x, qkv, o = b["x"], b["qkv"], b["o"]
         hq, hs, gq, gs = b["q"], b["qs"], b["gq"], b["gs"]
@@ -414,8 +415,11 @@ class VitEngine:
         for blk in self.blocks:
             layernorm_mxfp8(x, blk["n1w"], blk["n1b"], hq, hs, rows, D, D, count_dev=count, rows_per_count=N)
             linear_mxfp8(hq, hs, blk["wqkv_q"], blk["wqkv_s"], blk["bqkv"], qkv, m_dev=count, m_mul=N)
-            attention(qkv, cap, N, H, o, r_dev=count)
-            quant_mxfp8(o, hq, hs)
+            if H % 2 == 0:
+                attention_mxfp8(qkv, cap, N, H, hq, hs, r_dev=count)          # attention writes the proj operand directly
+            else:
+                attention(qkv, cap, N, H, o, r_dev=count)
+                quant_mxfp8(o, hq, hs)
             linear_mxfp8(hq, hs, blk["wproj_q"], blk["wproj_s"], blk["bproj"], x, flags=EPI_RES_F32, m_dev=count, m_mul=N)
             layernorm_mxfp8(x, blk["n2w"], blk["n2b"], hq, hs, rows, D, D, count_dev=count, rows_per_count=N)
             linear_mxfp8_q(hq, hs, blk["wfc1_q"], blk["wfc1_s"], blk["bfc1"], gq, gs, flags=EPI_GELU, m_dev=count, m_mul=N)
