@@ -1321,7 +1321,13 @@ static int linear_mx_impl(const void* Aq, long long lda, const void* Ascale, lon
     auto kern = gemm_mx_kernel<128, 128, 2, 2>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, (hipStream_t)stream, a);
+    if (t_time_start || t_time_stop) {
+        hipExtLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), (uint32_t)lds, (hipStream_t)stream, t_time_start,
+                              t_time_stop, 0, a);
+        t_time_start = t_time_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, (hipStream_t)stream, a);
+    }
     return yv_launch_status();
 }
 

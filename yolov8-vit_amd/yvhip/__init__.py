@@ -353,6 +353,19 @@ def _hip():
     return _HIP
 
 
+_EVENT_POOL: list = []
+
+
+def reserve_events(n: int):
+    """Create n HipEvents ahead of a timed region (hipEventCreate inside it would be host time on the measured path)."""
+    while len(_EVENT_POOL) < n:
+        _EVENT_POOL.append(HipEvent())
+
+
+def _timing_event() -> "HipEvent":
+    return _EVENT_POOL.pop() if _EVENT_POOL else HipEvent()
+
+
 class HipEvent:
     """Plain hipEvent_t (timing enabled) for launch-attached timestamps; elapsed_time() in ms like torch.cuda.Event."""
 
@@ -400,7 +413,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
         flags |= EPI_BIAS
     hook = LINEAR_HOOK
     if hook is not None:                     # bench.py: HIP events attached to the launch itself (hipExtLaunchKernel)
-        e0, e1 = HipEvent(), HipEvent()
+        e0, e1 = _timing_event(), _timing_event()
         check(lib.yv_set_launch_timing(e0.handle, e1.handle), "yv_set_launch_timing")
     check(lib.yv_linear(_p(a), a.stride(0), _p(w), _p(bias), Mr, N, K, _p(out), out.stride(0), _p(pos), tok, flags,
                         _p(m_dev), m_mul, _st()), "yv_linear")
@@ -709,8 +722,15 @@ def linear_mxfp8(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_sc
     N = wq.shape[0]
     if bias is not None:
         flags |= EPI_BIAS
+    hook = LINEAR_HOOK
+    if hook is not None:
+        e0, e1 = _timing_event(), _timing_event()
+        check(lib.yv_set_launch_timing(e0.handle, e1.handle), "yv_set_launch_timing")
     check(lib.yv_linear_mxfp8(_p(aq), aq.stride(0), _p(a_scale), a_scale.shape[1], _p(wq), _p(w_scale), w_scale.shape[1],
                               _p(bias), M, N, K, _p(out), out.stride(0), flags, _p(m_dev), m_mul, _st()), "yv_linear_mxfp8")
+    if hook is not None:
+        lib.yv_set_launch_timing(None, None)
+        hook(M, N, K, e0, e1)
     return out
 
 
@@ -730,9 +750,16 @@ def linear_mxfp8_q(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_
     N = wq.shape[0]
     if bias is not None:
         flags |= EPI_BIAS
+    hook = LINEAR_HOOK
+    if hook is not None:
+        e0, e1 = _timing_event(), _timing_event()
+        check(lib.yv_set_launch_timing(e0.handle, e1.handle), "yv_set_launch_timing")
     check(lib.yv_linear_mxfp8_q(_p(aq), aq.stride(0), _p(a_scale), a_scale.shape[1], _p(wq), _p(w_scale), w_scale.shape[1],
                                 _p(bias), M, N, K, flags, _p(m_dev), m_mul, _p(out_q), out_q.stride(0), _p(out_scale),
                                 out_scale.shape[1], _st()), "yv_linear_mxfp8_q")
+    if hook is not None:
+        lib.yv_set_launch_timing(None, None)
+        hook(M, N, K, e0, e1)
 
 
 def attention_mxfp8(qkv: torch.Tensor, R: int, N: int, H: int, out_q: torch.Tensor, out_scale: torch.Tensor,

@@ -13,6 +13,7 @@ device buffers.  Activations are NHWC bf16; concat / split / upsample never mate
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -315,6 +316,7 @@ class VitEngine:
         if dtype not in ("bf16", "mxfp8"):
             raise YvError("dtype must be 'bf16' or 'mxfp8'")
         self.dtype = dtype
+        self.fuse_attention_quant = os.environ.get("YV_MX_ATTN_FUSED", "1") == "1"     # A/B switch of the mxfp8 path
         self.P, self.D, self.L, self.H = vit_cfg(name)
         if self.D // self.H != 64:
             raise YvError("attention kernel is specialised for head dim 64")
@@ -415,7 +417,7 @@ class VitEngine:
         for blk in self.blocks:
             layernorm_mxfp8(x, blk["n1w"], blk["n1b"], hq, hs, rows, D, D, count_dev=count, rows_per_count=N)
             linear_mxfp8(hq, hs, blk["wqkv_q"], blk["wqkv_s"], blk["bqkv"], qkv, m_dev=count, m_mul=N)
-            if H % 2 == 0:
+            if H % 2 == 0 and self.fuse_attention_quant:
                 attention_mxfp8(qkv, cap, N, H, hq, hs, r_dev=count)          # attention writes the proj operand directly
             else:
                 attention(qkv, cap, N, H, o, r_dev=count)
