@@ -234,17 +234,8 @@ def main():
         # The classifier runs as two concurrent half-batches, so launches of the kernel overlap in time and each one's
         # event-to-event duration covers a period in which it owns only part of the chip.  Rate of the kernel = its
         # algorithmic flops / the time during which at least one launch of it is executing (union of the intervals).
-        iv = sorted((base_ev.elapsed_time(e0), base_ev.elapsed_time(e1)) for _, e0, e1 in recs)
-        busy, cur_s, cur_e = 0.0, None, None
-        for a, b in iv:
-            if cur_e is None or a > cur_e:
-                if cur_e is not None:
-                    busy += cur_e - cur_s
-                cur_s, cur_e = a, b
-            else:
-                cur_e = max(cur_e, b)
-        if cur_e is not None:
-            busy += cur_e - cur_s
+        from yvhip.dist import union_length
+        busy = union_length((base_ev.elapsed_time(e0), base_ev.elapsed_time(e1)) for _, e0, e1 in recs)
         achieved = flops / (busy * 1e-3) / 1e12 if busy > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

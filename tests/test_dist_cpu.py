@@ -53,3 +53,13 @@ def test_two_rank_gloo():
     for rank, t, merged in res:
         assert t == 2.0
         assert merged == [f"img{i:03d}" for i in range(33)]
+
+
+def test_union_length():
+    """Interval union used for the roofline of concurrently launched kernels."""
+    from yvhip.dist import union_length
+    assert union_length([]) == 0.0
+    assert union_length([(0.0, 1.0)]) == 1.0
+    assert union_length([(0.0, 1.0), (2.0, 3.5)]) == 2.5                       # disjoint
+    assert union_length([(2.0, 3.0), (0.0, 2.5), (2.9, 4.0)]) == 4.0           # overlapping, unsorted
+    assert union_length([(0.0, 5.0), (1.0, 2.0), (3.0, 4.0)]) == 5.0           # nested

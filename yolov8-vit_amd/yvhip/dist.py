@@ -73,3 +73,19 @@ class BucketReducer:
         for h in self.pending:
             h.wait()
         self.pending = []
+
+
+def union_length(intervals) -> float:
+    """Total length of the union of [start, end] intervals (bench.py: time during which at least one launch of the
+    dominant kernel is executing, from launch-attached event timestamps of concurrent streams)."""
+    busy, cur_s, cur_e = 0.0, None, None
+    for a, b in sorted(intervals):
+        if cur_e is None or a > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    if cur_e is not None:
+        busy += cur_e - cur_s
+    return busy
