@@ -144,6 +144,18 @@ int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, size_t img_s
  * out (B,S,S,3) u8: bilinear resample into the window, 114 elsewhere. */
 int yv_letterbox(const uint8_t* src, int B, int Hc, int Wc, const int32_t* geom, int S, uint8_t* out, void* stream);
 
+/* Training augmentation of classifier crops fused with the patch-embed operand builder: replaces the stochastic part
+ * of data_transforms['train'] (utils/trainClass.py:199-216: HorizontalFlip, RandomCrop+PadIfNeeded, ShiftScaleRotate,
+ * ChannelShuffle, OneOf[GridDistortion|ElasticTransform], CoarseDropout) that follows Resize + Normalize.
+ * x (B,3,S,S) f32 normalised crops; one host-drawn record per sample:
+ *   geo (B, 6 + 2S) f32: inverse affine {a0..a5} (u = a0*cx + a1*cy + a2, v = a3*cx + a4*cy + a5), then the per-axis
+ *                        distortion tables lutx[S], luty[S] (identity: lut[i] = i);
+ *   idx (B, 36 + 2S) i32: source channel of output channel 0..2, hole count (0..8), 8 holes {x1,y1,x2,y2} (exclusive
+ *                        right/bottom), then integer column / row tables mapx[S], mapy[S] (flip, crop offset + reflected pad).
+ * Sampling is bilinear with BORDER_REFLECT_101 in the flipped / crop-padded frame; holes are filled with 0.
+ * out (B*(S/P)^2, 3*P*P) bf16 patch-major rows (same layout as yv_crop_resize_norm layout 2). */
+int yv_augment_patchify(const float* x, int B, int S, int P, const float* geo, const int32_t* idx, void* out, void* stream);
+
 /* DFL decode + anchors + sigmoid (docs/YOLO_TensorRT_Technical.md:14-30,72-77).
  * Per scale s (3 scales, strides 8/16/32): box logits (B,Hs,Ws,64) f32 and class
  * logits (B,Hs,Ws,cls_ld) f32, NHWC.  Outputs boxes (B,A,4) f32 xyxy input pixels,

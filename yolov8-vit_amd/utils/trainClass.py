@@ -4,8 +4,8 @@ Hot-path pieces run on the HIP kernels: `build_model`/`Network_Wrapper` (ViT eng
 `LabelSmoothingCrossEntropy` + `FocalLoss` (fused loss kernel with its analytic gradient),
 `getCorrect` (device argmax), the eval transform and `crop_image`'s integer inflate.  `train_one_epoch` / `valid_one_epoch`
 run the native fine-tune step (yvhip.training).  The dataset front-end (`xml2pd`, `build_dataset`, `build_dataloader`,
-`deliver`, `train`, `retrain`) follows the reference on the host; ONNX export and the stochastic augmentation zoo
- are not rebuilt.
+`deliver`, `train`, `retrain`) follows the reference on the host; the stochastic training transforms
+run on the device (yvhip/augment.py, csrc/augment.hip); ONNX export is not rebuilt.
 """
 import json
 import math
@@ -126,11 +126,25 @@ class _EvalTransform:
         return {"image": x}
 
 
+class _TrainTransform(_EvalTransform):
+    """`data_transforms['train']` (utils/trainClass.py:199-216).  Called per item on the host it performs the
+    deterministic head of the sequence (Resize + Normalize, exactly the eval transform); the stochastic transforms
+    (flip, crop+pad, shift-scale-rotate, channel shuffle, grid / elastic distortion, coarse dropout) are drawn per
+    batch by `device_augment` and applied on the device by `train_one_epoch` while the batch is turned into the
+    patch-embed operand (yv_augment_patchify): the reference applies them to the normalised image as well, so moving
+    them behind the collate step changes nothing but where they run."""
+
+    def __init__(self, size):
+        super().__init__(size)
+        from yvhip.augment import TrainAugment
+        if size[0] != size[1]:
+            raise yvhip.YvError("the device augmentation needs a square CFG.img_size")
+        self.device_augment = TrainAugment(size[0])
+
+
 def build_transforms(CFG):
-    """Only the deterministic `valid_test` branch is on the hot path; the stochastic training
-    augmentations (utils/trainClass.py:199-216) are SURVEY.md 8(f) N4, not built."""
-    t = _EvalTransform(CFG.img_size)
-    return {"train": t, "valid_test": t}
+    """utils/trainClass.py:197-222: {'train': stochastic sequence, 'valid_test': Resize + Normalize}."""
+    return {"train": _TrainTransform(CFG.img_size), "valid_test": _EvalTransform(CFG.img_size)}
 
 
 # -------------------------------------------------------------------------- schedule / accuracy
@@ -229,6 +243,9 @@ def train_one_epoch(net, netp, trainloader, CELoss, optimizer, lr, batch_size, e
     tr = _trainer_for(net, optimizer)
     net.train()
     train_loss, correct, total = 0.0, 0, 0
+    # stochastic transforms of data_transforms['train'] run on the device (see _TrainTransform); a loader built with
+    # any other transform trains on exactly what it yields
+    aug = getattr(getattr(getattr(trainloader, "dataset", None), "transforms", None), "device_augment", None)
     for batch_idx, (inputs, targets, path) in enumerate(trainloader):
         if inputs.shape[0] < batch_size:
             continue
@@ -236,9 +253,14 @@ def train_one_epoch(net, netp, trainloader, CELoss, optimizer, lr, batch_size, e
         if optimizer is not None:
             for grp in optimizer.param_groups:
                 grp['lr'] = cur_lr
-        x = inputs.to(tr.dev).float()
+        x = inputs.to(tr.dev).float().contiguous()
         labels = targets.to(tr.dev).argmax(1).to(torch.int32).contiguous()
-        loss, logits = tr.step(patchify_bf16(x, tr.P_), labels, cur_lr)
+        if aug is not None:
+            geo, idx = aug.sample(x.shape[0])
+            patches = yvhip.augment_patchify(x, torch.from_numpy(geo).to(tr.dev), torch.from_numpy(idx).to(tr.dev), tr.P_)
+        else:
+            patches = patchify_bf16(x, tr.P_)
+        loss, logits = tr.step(patches, labels, cur_lr)
         eq, _ = getCorrect(logits.data, targets.to(logits.device).float().data)
         total += targets.size(0)
         correct += int(eq.sum())
@@ -362,9 +384,9 @@ def classExport(CFG, pretrained=None, modelName=None):
 def train(CFG, log=False, save_path="/app/utils/new_weight/best.pth"):
     """utils/trainClass.py:424-508: datasets from CFG.train_path / CFG.valid_path, model from CFG.pretrained (random
     init if that file is absent), CFG.epoch epochs of train_one_epoch + valid_one_epoch, best state dict to
-    /app/utils/new_weight/best.pth, result.json when `log`.  The stochastic training augmentations
-    (utils/trainClass.py:199-216) are not built: training crops get the random inflation of crop_image and the
-    deterministic resize + normalise."""
+    /app/utils/new_weight/best.pth, result.json when `log`.  Training crops get the random inflation of crop_image, the
+    deterministic resize + normalise on the host and the stochastic transforms of utils/trainClass.py:199-216 on the
+    device (see _TrainTransform)."""
     data_transforms = build_transforms(CFG)
     objects, objects_circle = xml2pd(CFG.train_path)
     valid_objects, valid_objects_circle = xml2pd(CFG.valid_path)

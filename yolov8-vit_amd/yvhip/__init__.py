@@ -70,6 +70,7 @@ _SIGS = {
     "yv_compact_crops": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "yv_crop_resize_norm": (_i, [_vp, _i, _i, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "yv_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "yv_augment_patchify": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "yv_optim_step": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "yv_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
@@ -296,6 +297,25 @@ def letterbox(src: torch.Tensor, geom: torch.Tensor, size: int) -> torch.Tensor:
     B, Hc, Wc, _ = src.shape
     out = torch.empty((B, size, size, 3), dtype=torch.uint8, device=src.device)
     check(lib.yv_letterbox(_p(src), B, Hc, Wc, _p(geom), size, _p(out), _st()), "yv_letterbox")
+    return out
+
+
+def augment_patchify(x: torch.Tensor, geo: torch.Tensor, idx: torch.Tensor, patch: int,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (B,3,S,S) f32 normalised crops + one augmentation record per sample (yvhip.augment) ->
+    (B*(S/P)^2, 3*P*P) bf16 patch-major rows."""
+    _chk_dev(x, geo, idx)
+    B, C, S, S2 = x.shape
+    if C != 3 or S != S2 or x.dtype != torch.float32 or not x.is_contiguous():
+        raise YvError("augment_patchify: x must be a contiguous (B,3,S,S) f32 tensor")
+    if tuple(geo.shape) != (B, 6 + 2 * S) or geo.dtype != torch.float32 or not geo.is_contiguous():
+        raise YvError("augment_patchify: geo must be (B, 6 + 2S) f32")
+    if tuple(idx.shape) != (B, 36 + 2 * S) or idx.dtype != torch.int32 or not idx.is_contiguous():
+        raise YvError("augment_patchify: idx must be (B, 36 + 2S) i32")
+    g = S // patch
+    if out is None:
+        out = torch.empty((B * g * g, 3 * patch * patch), dtype=torch.bfloat16, device=x.device)
+    check(lib.yv_augment_patchify(_p(x), B, S, patch, _p(geo), _p(idx), _p(out), _st()), "yv_augment_patchify")
     return out
 
 
