@@ -156,6 +156,17 @@ int yv_letterbox(const uint8_t* src, int B, int Hc, int Wc, const int32_t* geom,
  * out (B*(S/P)^2, 3*P*P) bf16 patch-major rows (same layout as yv_crop_resize_norm layout 2). */
 int yv_augment_patchify(const float* x, int B, int S, int P, const float* geo, const int32_t* idx, void* out, void* stream);
 
+/* Detector training augmentation, what `model.train()` (utils/trainYolo.py:28) applies by default: Mosaic(4) ->
+ * RandomPerspective(scale, translate) -> HSV gains -> horizontal flip in one gather pass per output image.
+ * tiles (n_tiles,S,S,3) u8: sources resized to long side S in the top-left corner of their slot (yv_letterbox, fill 114).
+ *   rec_f (B,6) f32: inverse affine, output pixel -> mosaic-canvas coordinate;
+ *   rec_i (B,34) i32: {tiles used (1..4), flip}, then per tile {id, x1a, y1a, x2a, y2a, x1b, y1b, 0}: the canvas rectangle
+ *                     [x1a,x2a) x [y1a,y2a) shows tile `id` starting at its pixel (x1b, y1b);
+ *   lut (B,3,256) u8: hue / saturation / value tables applied in 8-bit HSV (H in [0,180)).
+ * Bilinear; canvas pixels outside every rectangle are 114.  out (B,S,S,3) u8 NHWC (the detector's input layout). */
+int yv_mosaic_augment(const uint8_t* tiles, int n_tiles, int B, int S, const float* rec_f, const int32_t* rec_i,
+                      const uint8_t* lut, uint8_t* out, void* stream);
+
 /* DFL decode + anchors + sigmoid (docs/YOLO_TensorRT_Technical.md:14-30,72-77).
  * Per scale s (3 scales, strides 8/16/32): box logits (B,Hs,Ws,64) f32 and class
  * logits (B,Hs,Ws,cls_ld) f32, NHWC.  Outputs boxes (B,A,4) f32 xyxy input pixels,

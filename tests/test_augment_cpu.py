@@ -148,3 +148,111 @@ def test_train_transform_carries_the_device_stage():
     assert hasattr(t["train"], "device_augment") and not hasattr(t["valid_test"], "device_augment")
     img = np.random.default_rng(0).integers(0, 256, (37, 51, 3), dtype=np.uint8)
     np.testing.assert_array_equal(t["train"](image=img)["image"], t["valid_test"](image=img)["image"])
+
+
+# ------------------------------------------------------------------------------------- detector augmentation (host side)
+def _gray_tiles(sizes, S, seed=0):
+    """Tiles the way yv_letterbox leaves them: the resized image in the top-left corner of an S x S slot, 114 elsewhere.
+    Grey levels only: 8-bit HSV is the identity on them, so geometry can be compared exactly."""
+    rng = np.random.default_rng(seed)
+    tiles = np.full((len(sizes), S, S, 3), 114, dtype=np.uint8)
+    ims = []
+    for k, (w, h) in enumerate(sizes):
+        g = rng.integers(0, 256, (h, w, 1), dtype=np.uint8).repeat(3, axis=2)
+        tiles[k, :h, :w] = g
+        ims.append(g)
+    return tiles, ims
+
+
+@pytest.mark.parametrize("centre,flip", [((64, 64), False), ((40, 90), True), ((95, 33), False), ((32, 32), True), ((96, 96), False)])
+def test_mosaic_record_equals_explicit_canvas(centre, flip):
+    """scale 1, translate (.5,.5): the output is the central S x S window of the published 2S canvas."""
+    from oracle import yolo_augment as oy
+    from yvhip.yolo_augment import build_record, hsv_tables
+    S = 64
+    sizes = [(64, 48), (40, 64), (64, 64), (30, 20)]
+    tiles, ims = _gray_tiles(sizes, S)
+    plan = dict(mosaic=True, sources=[0, 1, 2, 3], centre=centre, scale=1.0, translate=(0.5, 0.5), hsv=[1.0, 1.0, 1.0], flip=flip)
+    rec_f, rec_i, lut, M, offs, canvas = build_record(plan, sizes, [0, 1, 2, 3], S)
+    want, pads = oy.explicit_mosaic(ims, centre, S)
+    want = want[S // 2:S // 2 + S, S // 2:S // 2 + S]
+    if flip:
+        want = want[:, ::-1]
+    np.testing.assert_array_equal(oy.apply_record(tiles, rec_f, rec_i, lut, S), want)
+    assert offs == pads and canvas == 2 * S
+    np.testing.assert_array_equal(lut, hsv_tables([1, 1, 1]))
+
+
+def test_single_image_record_is_centred_letterbox():
+    from oracle import yolo_augment as oy
+    from yvhip.yolo_augment import build_record
+    S = 64
+    tiles, ims = _gray_tiles([(64, 40)], S, 3)
+    plan = dict(mosaic=False, sources=[0], scale=1.0, translate=(0.5, 0.5), hsv=[1.0, 1.0, 1.0], flip=False)
+    rec_f, rec_i, lut, M, offs, canvas = build_record(plan, [(64, 40)], [0], S)
+    want = np.full((S, S, 3), 114, np.uint8)
+    want[12:52] = ims[0]
+    np.testing.assert_array_equal(oy.apply_record(tiles, rec_f, rec_i, lut, S), want)
+    assert offs == [(0, 12)] and canvas == S
+
+
+def test_hsv_statement_against_colorsys():
+    """The 8-bit HSV round trip with gains: within the 8-bit hue quantisation of the float conversion."""
+    import colorsys
+    from oracle import yolo_augment as oy
+    from yvhip.yolo_augment import hsv_tables
+    S = 16
+    rng = np.random.default_rng(1)
+    tiles = rng.integers(0, 256, (1, S, S, 3), dtype=np.uint8)
+    tiles[0, 0, :4] = [(255, 0, 0), (0, 255, 0), (0, 0, 255), (255, 255, 255)]
+    rec_i = np.zeros(34, np.int32)
+    rec_i[0], rec_i[2:9] = 1, (0, 0, 0, S, S, 0, 0)
+    ident = np.array([1, 0, 0, 0, 1, 0], np.float32)
+    out = oy.apply_record(tiles, ident, rec_i, hsv_tables([1, 1, 1]), S)
+    assert np.abs(out.astype(int) - tiles[0].astype(int)).max() <= 5          # hue is quantised to 2 degree steps: up to 255/60 levels
+    np.testing.assert_array_equal(out[0, :4], tiles[0, 0, :4])
+    gains = [1.0, 0.5, 0.8]
+    out = oy.apply_record(tiles, ident, rec_i, hsv_tables(gains), S)
+    for (y, x) in [(1, 1), (5, 9), (15, 15), (0, 0)]:
+        r, g, b = (tiles[0, y, x] / 255.0)
+        h, s, v = colorsys.rgb_to_hsv(r, g, b)
+        want = np.array(colorsys.hsv_to_rgb(h, s * gains[1], v * gains[2])) * 255
+        assert np.abs(out[y, x] - want).max() <= 6, (out[y, x], want)
+
+
+def test_transform_boxes():
+    from yvhip.yolo_augment import affine_matrix, transform_boxes
+    S = 64
+    M = affine_matrix(2 * S, S, 1.0, 0.5, 0.5)                          # window [32, 96) of the canvas
+    boxes = np.array([[40, 40, 60, 70], [0, 0, 33, 33], [90, 90, 128, 128], [50, 50, 51.5, 80], [20, 60, 100, 64.5]], float)
+    labels = np.arange(5)
+    nb, nl = transform_boxes(boxes, labels, M, 1.0, S, flip=False)
+    # box 1: 1 x 1 px left after clipping (too small); box 3: 1.5 px wide; box 2 keeps 6 x 6 of 38 x 38 (area < 10 %)
+    assert nl.tolist() == [0, 4]
+    np.testing.assert_allclose(nb[0], [8, 8, 28, 38])
+    np.testing.assert_allclose(nb[1], [0, 28, 64, 32.5])
+    fb, _ = transform_boxes(boxes, labels, M, 1.0, S, flip=True)
+    np.testing.assert_allclose(fb[0], [36, 8, 56, 38])
+    M2 = affine_matrix(2 * S, S, 0.5, 0.5, 0.5)                         # whole canvas at half size
+    nb, _ = transform_boxes(boxes[:1], labels[:1], M2, 0.5, S, flip=False)
+    np.testing.assert_allclose(nb[0], [20, 20, 30, 35])
+
+
+def test_det_plan_ranges():
+    from yvhip.yolo_augment import DetAugment, hsv_tables, tile_geometry
+    S = 640
+    aug = DetAugment(S, seed=5)
+    flips = 0
+    for k in range(2000):
+        p = aug.plan(k % 7, 7)
+        assert p["mosaic"] and len(p["sources"]) == 4 and p["sources"][0] == k % 7 and all(0 <= s < 7 for s in p["sources"])
+        assert all(S // 2 <= c <= 3 * S // 2 for c in p["centre"])
+        assert 0.5 <= p["scale"] <= 1.5 and all(0.4 <= t <= 0.6 for t in p["translate"])
+        assert abs(p["hsv"][0] - 1) <= 0.015 and abs(p["hsv"][1] - 1) <= 0.7 and abs(p["hsv"][2] - 1) <= 0.4
+        flips += p["flip"]
+    assert abs(flips / 2000 - 0.5) < 0.04
+    assert not aug.plan(0, 7, use_mosaic=False)["mosaic"]
+    t = hsv_tables([1.01, 1.7, 0.6])
+    assert t.shape == (3, 256) and t[0].max() < 180 and t[1][200] == 255 and t[2][100] == 60
+    assert tile_geometry(1280, 720, 640) == (640, 360) and tile_geometry(100, 50, 640) == (640, 320)
+    assert tile_geometry(640, 640, 640) == (640, 640) and tile_geometry(333, 500, 640) == (427, 640)

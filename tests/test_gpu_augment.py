@@ -132,3 +132,83 @@ def test_train_one_epoch_applies_the_device_stage(yv, monkeypatch, tmp_path):
     correct = tc.train_one_epoch(net, None, loader, tc.build_loss, None, [0.01], 4, 0, 2, True, DEV)
     assert len(calls) == 2 and calls[0] == ((4, 3, 224, 224), (4, 6 + 448))
     assert 0 <= correct <= 8
+
+
+# ------------------------------------------------------------------------------------------- detector augmentation
+def _mosaic_inputs(S, B, n_tiles, seed):
+    from yvhip.yolo_augment import DetAugment, build_record, tile_geometry
+    rng = np.random.default_rng(seed)
+    raw = [(int(rng.integers(S // 3, 2 * S)), int(rng.integers(S // 3, 2 * S))) for _ in range(n_tiles)]
+    sizes = [tile_geometry(w, h, S) for w, h in raw]
+    tiles = np.full((n_tiles, S, S, 3), 114, np.uint8)
+    for k, (w, h) in enumerate(sizes):
+        tiles[k, :h, :w] = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    aug = DetAugment(S, seed=seed)
+    rf, ri, lut = [], [], []
+    for b in range(B):
+        p = aug.plan(b % n_tiles, n_tiles, use_mosaic=(b % 4 != 3))
+        f, i, l, _, _, _ = build_record(p, [sizes[s] for s in p["sources"]], p["sources"], S)
+        rf.append(f); ri.append(i); lut.append(l)
+    return tiles, np.stack(rf), np.stack(ri), np.stack(lut)
+
+
+@pytest.mark.parametrize("S,B", [(64, 16), (640, 2)])
+def test_mosaic_kernel_bit_exact(yv, S, B):
+    from oracle import yolo_augment as oy
+    tiles, rf, ri, lut = _mosaic_inputs(S, B, 6, seed=S)
+    out = yv.mosaic_augment(*(torch.from_numpy(a).to(DEV) for a in (tiles, rf, ri, lut)))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    assert out.shape == (B, S, S, 3)
+    for b in range(B):
+        np.testing.assert_array_equal(out[b], oy.apply_record(tiles, rf[b], ri[b], lut[b], S), err_msg=f"image {b}")
+
+
+def test_mosaic_kernel_hostile_records(yv):
+    from oracle import yolo_augment as oy
+    S, B = 32, 4
+    tiles, rf, ri, lut = _mosaic_inputs(S, B, 4, seed=9)
+    rf[0] = (np.nan, 1e30, -1e30, np.inf, 0, 1)
+    ri[1, 2::8] = (99, -5, 4, 7)                                   # tile ids outside the tile array
+    ri[2, 0] = 1000
+    ri[2, 2:] = np.random.default_rng(0).integers(-200, 200, 32)
+    ri[2, 2::8] = (0, 1, 2, 3)
+    lut[3] = np.random.default_rng(1).integers(0, 256, (3, 256), dtype=np.uint8)
+    out = yv.mosaic_augment(*(torch.from_numpy(a).to(DEV) for a in (tiles, rf, ri, lut))).cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(out[b], oy.apply_record(tiles, rf[b], ri[b], lut[b], S), err_msg=f"image {b}")
+
+
+def test_augment_batch_from_files(yv, tmp_path):
+    """Files -> tiles (yv_letterbox) -> composed batch: labels stay inside the image and follow their objects: a bright
+    rectangle on a dark image must still be bright inside its transformed box."""
+    from PIL import Image
+    from yvhip.yolo_augment import DetAugment, augment_batch
+    S, n = 128, 5
+    rng = np.random.default_rng(0)
+    (tmp_path / "images").mkdir(); (tmp_path / "labels").mkdir()
+    samples = []
+    for i in range(n):
+        w, h = int(rng.integers(90, 200)), int(rng.integers(90, 200))
+        img = np.full((h, w, 3), 20, np.uint8)
+        x0, y0, bw, bh = int(rng.integers(5, w // 2)), int(rng.integers(5, h // 2)), w // 3, h // 3
+        img[y0:y0 + bh, x0:x0 + bw] = 235
+        ip, lp = tmp_path / "images" / f"a{i}.png", tmp_path / "labels" / f"a{i}.txt"
+        Image.fromarray(img).save(ip)
+        lp.write_text(f"{i % 3} {(x0 + bw / 2) / w} {(y0 + bh / 2) / h} {bw / w} {bh / h}\n")
+        samples.append((str(ip), str(lp)))
+    aug = DetAugment(S, seed=4)
+    checked = 0
+    for use_mosaic in (True, False):
+        img, gtb, gtl, gtn = augment_batch(samples, range(4), aug, 8, DEV, use_mosaic=use_mosaic)
+        assert img.shape == (4, S, S, 3) and img.dtype == torch.uint8 and img.is_cuda
+        im = img.cpu().numpy().astype(np.float32).max(axis=3)      # the value channel survives the hue / saturation gains
+        for b in range(4):
+            for j in range(int(gtn[b])):
+                x1, y1, x2, y2 = gtb[b, j].tolist()
+                assert 0 <= x1 < x2 <= S and 0 <= y1 < y2 <= S and 0 <= int(gtl[b, j]) < 3
+                if x2 - x1 >= 6 and y2 - y1 >= 6:
+                    inner = im[b, int(y1) + 2:int(y2) - 2, int(x1) + 2:int(x2) - 2]
+                    assert inner.mean() > 100, (use_mosaic, b, j, inner.mean())
+                    checked += 1
+    assert checked >= 6

@@ -194,13 +194,17 @@ def test_train_yolo_surface(tmp_path):
     logs = []
     res = ty.train(epochs=3, batch=2, data=str(tmp_path / "config.yaml"), size=128, save=str(tmp_path / "w" / "best.pth"),
                    log=logs.append)
-    assert len(res["epochs"]) == 3 and res["epochs"][0]["steps"] == n_train // 2 and any("augmentation" in x for x in res["not_built"])
+    assert len(res["epochs"]) == 3 and res["epochs"][0]["steps"] == n_train // 2 and isinstance(res["not_built"], list)
     n_val = len(list((root / "images" / "val").glob("*.png")))
     for v in (res["val_before"], res["val_after"]):
         assert v["images"] == n_val and v["instances"] == n_val and 0.0 <= v["map50_95"] <= v["map50"] <= 0.995
     assert res["optimizer"] == "adamw" and res["lr0"] == pytest.approx(0.001111) and res["accumulate"] == 32   # optimizer=auto
     assert all(np.isfinite(e["loss"]) for e in res["epochs"])
     assert res["epochs"][0]["lr"] == pytest.approx(0.001111) and res["epochs"][2]["lr"] < res["epochs"][1]["lr"]
+    # validation after every epoch, best-fitness checkpoint next to the last one
+    assert all("fitness" in e and 0.0 <= e["map50_95"] <= e["map50"] for e in res["epochs"])
+    assert res["best_fitness"] == max(e["fitness"] for e in res["epochs"]) and 0 <= res["best_epoch"] < 3
+    assert os.path.exists(str(tmp_path / "w" / "best_last.pth"))
     sd = torch.load(res["weights"], map_location="cpu", weights_only=True)
     assert "model.0.conv.weight" in sd and "model.22.cv3.2.2.bias" in sd and sd["model.0.bn.running_var"].shape == (16,)
     res2 = ty.train(epochs=1, batch=2, data=str(tmp_path / "config.yaml"), size=128, weights=res["weights"],

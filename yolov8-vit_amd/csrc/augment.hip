@@ -113,3 +113,115 @@ extern "C" int yv_augment_patchify(const float* x, int B, int S, int P, const fl
         x, S, P, geo, idx, (uint16_t*)out);
     return yv_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Detector training augmentation (what `model.train()` of utils/trainYolo.py:28 applies by default):
+// Mosaic(4) -> RandomPerspective(scale, translate) -> HSV gains -> horizontal flip, as ONE gather pass per output image.
+// Sources are "tiles": images already resized to long side S in the top-left corner of an S x S slot (yv_letterbox).
+// The 2S x 2S mosaic canvas is never built: a canvas pixel is looked up in the (at most four) placement rectangles.
+//   rec_f (B,6)  f32: inverse affine, output pixel -> canvas coordinate
+//   rec_i (B,34) i32: {n_tiles, flip} then per tile {tile id, x1a, y1a, x2a, y2a, x1b, y1b, 0}: canvas rectangle
+//                     [x1a,x2a) x [y1a,y2a) shows the tile from (x1b, y1b)
+//   lut   (B,3,256) u8: hue / saturation / value tables applied in 8-bit HSV (H in [0,180))
+// Bilinear taps outside every rectangle read the fill value 114.  f32 arithmetic, one rounding per operation, in the
+// order oracle/yolo_augment.py states.
+namespace {
+
+constexpr int MOS_THREADS = 256;
+
+__device__ __forceinline__ float mos_tap(const uint8_t* __restrict__ tiles, const int32_t* __restrict__ ri, int nt, int n_tiles_total,
+                                         int S, int i, int j, int c) {
+    for (int t = 0; t < nt; ++t) {
+        const int32_t* q = ri + 2 + t * 8;
+        if (i >= q[1] && i < q[3] && j >= q[2] && j < q[4]) {
+            const int id = q[0], sx = i - q[1] + q[5], sy = j - q[2] + q[6];
+            if (id < 0 || id >= n_tiles_total || sx < 0 || sx >= S || sy < 0 || sy >= S) return 114.0f;
+            return (float)tiles[(((size_t)id * S + sy) * S + sx) * 3 + c];
+        }
+    }
+    return 114.0f;
+}
+
+__device__ __forceinline__ float round_half_up(float v) { return floorf(__fadd_rn(v, 0.5f)); }
+
+__global__ __launch_bounds__(MOS_THREADS) void mosaic_kernel(const uint8_t* __restrict__ tiles, int n_tiles_total, int S,
+                                                             const float* __restrict__ rec_f, const int32_t* __restrict__ rec_i,
+                                                             const uint8_t* __restrict__ lut, uint8_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * MOS_THREADS + threadIdx.x;
+    if (p >= S * S) return;
+    const int y = p / S, x = p - y * S;
+    const float* a = rec_f + (size_t)b * 6;
+    const int32_t* ri = rec_i + (size_t)b * 34;
+    int nt = ri[0];
+    nt = nt < 0 ? 0 : (nt > 4 ? 4 : nt);
+    const float xs = (float)(ri[1] ? S - 1 - x : x), ys = (float)y;
+    float u = __fadd_rn(__fadd_rn(__fmul_rn(a[0], xs), __fmul_rn(a[1], ys)), a[2]);
+    float v = __fadd_rn(__fadd_rn(__fmul_rn(a[3], xs), __fmul_rn(a[4], ys)), a[5]);
+    const float lim = (float)(8 * S);
+    u = fminf(fmaxf(u, -lim), lim);
+    v = fminf(fmaxf(v, -lim), lim);
+    const float uf = floorf(u), vf = floorf(v);
+    const float fx = __fsub_rn(u, uf), fy = __fsub_rn(v, vf);
+    const float gx = __fsub_rn(1.0f, fx), gy = __fsub_rn(1.0f, fy);
+    const int i0 = (int)uf, j0 = (int)vf;
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v00 = mos_tap(tiles, ri, nt, n_tiles_total, S, i0, j0, c), v01 = mos_tap(tiles, ri, nt, n_tiles_total, S, i0 + 1, j0, c);
+        const float v10 = mos_tap(tiles, ri, nt, n_tiles_total, S, i0, j0 + 1, c), v11 = mos_tap(tiles, ri, nt, n_tiles_total, S, i0 + 1, j0 + 1, c);
+        const float top = __fadd_rn(__fmul_rn(v00, gx), __fmul_rn(v01, fx));
+        const float bot = __fadd_rn(__fmul_rn(v10, gx), __fmul_rn(v11, fx));
+        rgb[c] = fminf(fmaxf(round_half_up(__fadd_rn(__fmul_rn(top, gy), __fmul_rn(bot, fy))), 0.0f), 255.0f);
+    }
+    // 8-bit HSV: V = max, S = 255 * (V - min) / V, H = half degrees in [0,180)
+    const float R = rgb[0], G = rgb[1], Bc = rgb[2];
+    const float vmax = fmaxf(R, fmaxf(G, Bc)), vmin = fminf(R, fminf(G, Bc));
+    const float diff = __fsub_rn(vmax, vmin);
+    float h = 0.0f, s = 0.0f;
+    if (vmax > 0.0f) s = round_half_up(__fdiv_rn(__fmul_rn(255.0f, diff), vmax));
+    if (diff > 0.0f) {
+        if (vmax == R) h = __fdiv_rn(__fmul_rn(60.0f, __fsub_rn(G, Bc)), diff);
+        else if (vmax == G) h = __fadd_rn(120.0f, __fdiv_rn(__fmul_rn(60.0f, __fsub_rn(Bc, R)), diff));
+        else h = __fadd_rn(240.0f, __fdiv_rn(__fmul_rn(60.0f, __fsub_rn(R, G)), diff));
+        if (h < 0.0f) h = __fadd_rn(h, 360.0f);
+    }
+    int h8 = (int)round_half_up(__fmul_rn(h, 0.5f));
+    if (h8 >= 180) h8 -= 180;
+    const uint8_t* l = lut + (size_t)b * 768;
+    const float H2 = (float)l[h8], S2 = (float)l[256 + (int)s], V2 = (float)l[512 + (int)vmax];
+    // back: sector = H / 30 (half degrees), f = fractional part
+    const float hs = __fdiv_rn(H2, 30.0f);
+    const float sec = floorf(hs);
+    const float f = __fsub_rn(hs, sec);
+    const float sn = __fdiv_rn(S2, 255.0f);
+    const float pp = __fmul_rn(V2, __fsub_rn(1.0f, sn));
+    const float qq = __fmul_rn(V2, __fsub_rn(1.0f, __fmul_rn(sn, f)));
+    const float tt = __fmul_rn(V2, __fsub_rn(1.0f, __fmul_rn(sn, __fsub_rn(1.0f, f))));
+    const int si = ((int)sec) % 6;
+    float r2, g2, b2;
+    switch (si) {
+        case 0: r2 = V2; g2 = tt; b2 = pp; break;
+        case 1: r2 = qq; g2 = V2; b2 = pp; break;
+        case 2: r2 = pp; g2 = V2; b2 = tt; break;
+        case 3: r2 = pp; g2 = qq; b2 = V2; break;
+        case 4: r2 = tt; g2 = pp; b2 = V2; break;
+        default: r2 = V2; g2 = pp; b2 = qq; break;
+    }
+    uint8_t* o = out + (((size_t)b * S + y) * S + x) * 3;
+    o[0] = (uint8_t)fminf(fmaxf(round_half_up(r2), 0.0f), 255.0f);
+    o[1] = (uint8_t)fminf(fmaxf(round_half_up(g2), 0.0f), 255.0f);
+    o[2] = (uint8_t)fminf(fmaxf(round_half_up(b2), 0.0f), 255.0f);
+}
+
+}  // namespace
+
+extern "C" int yv_mosaic_augment(const uint8_t* tiles, int n_tiles, int B, int S, const float* rec_f, const int32_t* rec_i,
+                                 const uint8_t* lut, uint8_t* out, void* stream) {
+    if (!tiles || !rec_f || !rec_i || !lut || !out) return YV_ERR_ARG;
+    if (n_tiles <= 0 || B < 0 || S <= 0) return YV_ERR_ARG;
+    if (B == 0) return YV_OK;
+    mosaic_kernel<<<dim3((unsigned)((S * S + MOS_THREADS - 1) / MOS_THREADS), (unsigned)B), dim3(MOS_THREADS), 0,
+                    (hipStream_t)stream>>>(tiles, n_tiles, S, rec_f, rec_i, lut, out);
+    return yv_launch_status();
+}

@@ -71,6 +71,7 @@ _SIGS = {
     "yv_crop_resize_norm": (_i, [_vp, _i, _i, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "yv_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "yv_augment_patchify": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "yv_mosaic_augment": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "yv_optim_step": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "yv_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
@@ -316,6 +317,24 @@ def augment_patchify(x: torch.Tensor, geo: torch.Tensor, idx: torch.Tensor, patc
     if out is None:
         out = torch.empty((B * g * g, 3 * patch * patch), dtype=torch.bfloat16, device=x.device)
     check(lib.yv_augment_patchify(_p(x), B, S, patch, _p(geo), _p(idx), _p(out), _st()), "yv_augment_patchify")
+    return out
+
+
+def mosaic_augment(tiles: torch.Tensor, rec_f: torch.Tensor, rec_i: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
+    """tiles (N,S,S,3) u8 + one record per output image (yvhip.yolo_augment) -> (B,S,S,3) u8 augmented detector inputs."""
+    _chk_dev(tiles, rec_f, rec_i, lut)
+    N, S, S2, C = tiles.shape
+    B = rec_f.shape[0]
+    if C != 3 or S != S2 or tiles.dtype != torch.uint8 or not tiles.is_contiguous():
+        raise YvError("mosaic_augment: tiles must be a contiguous (N,S,S,3) u8 tensor")
+    if tuple(rec_f.shape) != (B, 6) or rec_f.dtype != torch.float32 or not rec_f.is_contiguous():
+        raise YvError("mosaic_augment: rec_f must be (B,6) f32")
+    if tuple(rec_i.shape) != (B, 34) or rec_i.dtype != torch.int32 or not rec_i.is_contiguous():
+        raise YvError("mosaic_augment: rec_i must be (B,34) i32")
+    if tuple(lut.shape) != (B, 3, 256) or lut.dtype != torch.uint8 or not lut.is_contiguous():
+        raise YvError("mosaic_augment: lut must be (B,3,256) u8")
+    out = torch.empty((B, S, S, 3), dtype=torch.uint8, device=tiles.device)
+    check(lib.yv_mosaic_augment(_p(tiles), N, B, S, _p(rec_f), _p(rec_i), _p(lut), _p(out), _st()), "yv_mosaic_augment")
     return out
 
 
