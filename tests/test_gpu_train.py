@@ -153,7 +153,7 @@ def test_trainer_gradients_vs_autograd(yv, name, R):
         worst[k] = rel_l2(got[k].cpu(), v)
     bad = {k: e for k, e in worst.items() if e > 1e-1}
     # bf16 forward (logit rel. error ~1e-2) moves dlogits and flips a few ReLU masks of the 1000-d head: the
-    # gradient error is a uniform 2-6 % per tensor (tools/grad_error_table.py), not growing with depth
+    # gradient error is a uniform 2-6 % per tensor (tests/diagnostics/grad_error_table.py), not growing with depth
     assert not bad, bad
 
 
