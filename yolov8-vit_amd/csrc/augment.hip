@@ -25,11 +25,14 @@ namespace {
 
 constexpr int AUG_THREADS = 128;
 
+// cv2.BORDER_REFLECT_101 index for |i| <= 4n + 1 (the coordinates are clamped to that range): folds instead of a division
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
     const int per = 2 * n - 2;
-    int m = i % per;
-    if (m < 0) m += per;
+    int m = i < 0 ? -i : i;                       // the pattern is even
+#pragma unroll
+    for (int k = 0; k < 3; ++k) m = m >= per ? m - per : m;        // |i| <= 4n + 1 < 3 * per for n >= 4; smaller n: loop below
+    while (m >= per) m -= per;
     return m < n ? m : per - m;
 }
 
@@ -129,17 +132,20 @@ namespace {
 
 constexpr int MOS_THREADS = 256;
 
-__device__ __forceinline__ float mos_tap(const uint8_t* __restrict__ tiles, const int32_t* __restrict__ ri, int nt, int n_tiles_total,
-                                         int S, int i, int j, int c) {
+// one canvas pixel, all three channels: the first placement rectangle that contains (i, j) decides
+__device__ __forceinline__ void mos_tap(const uint8_t* __restrict__ tiles, const int32_t* __restrict__ ri, int nt, int n_tiles_total,
+                                        int S, int i, int j, float (&px)[3]) {
+    px[0] = px[1] = px[2] = 114.0f;
     for (int t = 0; t < nt; ++t) {
         const int32_t* q = ri + 2 + t * 8;
         if (i >= q[1] && i < q[3] && j >= q[2] && j < q[4]) {
             const int id = q[0], sx = i - q[1] + q[5], sy = j - q[2] + q[6];
-            if (id < 0 || id >= n_tiles_total || sx < 0 || sx >= S || sy < 0 || sy >= S) return 114.0f;
-            return (float)tiles[(((size_t)id * S + sy) * S + sx) * 3 + c];
+            if (id < 0 || id >= n_tiles_total || sx < 0 || sx >= S || sy < 0 || sy >= S) return;
+            const uint8_t* p = tiles + (((size_t)id * S + sy) * S + sx) * 3;
+            px[0] = (float)p[0]; px[1] = (float)p[1]; px[2] = (float)p[2];
+            return;
         }
     }
-    return 114.0f;
 }
 
 __device__ __forceinline__ float round_half_up(float v) { return floorf(__fadd_rn(v, 0.5f)); }
@@ -165,13 +171,15 @@ __global__ __launch_bounds__(MOS_THREADS) void mosaic_kernel(const uint8_t* __re
     const float fx = __fsub_rn(u, uf), fy = __fsub_rn(v, vf);
     const float gx = __fsub_rn(1.0f, fx), gy = __fsub_rn(1.0f, fy);
     const int i0 = (int)uf, j0 = (int)vf;
-    float rgb[3];
+    float rgb[3], t00[3], t01[3], t10[3], t11[3];
+    mos_tap(tiles, ri, nt, n_tiles_total, S, i0, j0, t00);
+    mos_tap(tiles, ri, nt, n_tiles_total, S, i0 + 1, j0, t01);
+    mos_tap(tiles, ri, nt, n_tiles_total, S, i0, j0 + 1, t10);
+    mos_tap(tiles, ri, nt, n_tiles_total, S, i0 + 1, j0 + 1, t11);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float v00 = mos_tap(tiles, ri, nt, n_tiles_total, S, i0, j0, c), v01 = mos_tap(tiles, ri, nt, n_tiles_total, S, i0 + 1, j0, c);
-        const float v10 = mos_tap(tiles, ri, nt, n_tiles_total, S, i0, j0 + 1, c), v11 = mos_tap(tiles, ri, nt, n_tiles_total, S, i0 + 1, j0 + 1, c);
-        const float top = __fadd_rn(__fmul_rn(v00, gx), __fmul_rn(v01, fx));
-        const float bot = __fadd_rn(__fmul_rn(v10, gx), __fmul_rn(v11, fx));
+        const float top = __fadd_rn(__fmul_rn(t00[c], gx), __fmul_rn(t01[c], fx));
+        const float bot = __fadd_rn(__fmul_rn(t10[c], gx), __fmul_rn(t11[c], fx));
         rgb[c] = fminf(fmaxf(round_half_up(__fadd_rn(__fmul_rn(top, gy), __fmul_rn(bot, fy))), 0.0f), 255.0f);
     }
     // 8-bit HSV: V = max, S = 255 * (V - min) / V, H = half degrees in [0,180)
