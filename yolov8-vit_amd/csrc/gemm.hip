@@ -511,8 +511,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
     if (i >= (long long)g.M * n4) return;
     const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < g.splitk; ++s) {
-        const float4 p = *(const float4*)(g.partial + ((long long)s * g.M + m) * g.N + n);
+    // four slices per trip, loads first: a pure read pass lives on the loads in flight; summation order unchanged
+    const float* base = g.partial + (long long)m * g.N + n;
+    const long long slice = (long long)g.M * g.N;
+    int s = 0;
+    for (; s + 3 < g.splitk; s += 4) {
+        const float4 p0 = *(const float4*)(base + (s + 0) * slice), p1 = *(const float4*)(base + (s + 1) * slice);
+        const float4 p2 = *(const float4*)(base + (s + 2) * slice), p3 = *(const float4*)(base + (s + 3) * slice);
+        v.x += p0.x; v.y += p0.y; v.z += p0.z; v.w += p0.w;
+        v.x += p1.x; v.y += p1.y; v.z += p1.z; v.w += p1.w;
+        v.x += p2.x; v.y += p2.y; v.z += p2.z; v.w += p2.w;
+        v.x += p3.x; v.y += p3.y; v.z += p3.z; v.w += p3.w;
+    }
+    for (; s < g.splitk; ++s) {
+        const float4 p = *(const float4*)(base + s * slice);
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
     const int flags = g.flags;

@@ -70,15 +70,15 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(RedArgs a) {
         const long long r0 = (long long)blockIdx.x * a.rows_per_chunk;
         long long r1 = r0 + a.rows_per_chunk;
         r1 = r1 < a.T ? r1 : a.T;
-        for (long long r = r0 + lane_r; r < r1; r += rp) {
+        auto accumulate = [&](const uint4& zq, const uint4& dq) {
             float z[8];
-            unpack8(*(const uint4*)(a.z + r * a.ldz + g * 8), z);
+            unpack8(zq, z);
             if (MODE == 0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { s0[i] += z[i]; s1[i] += z[i] * z[i]; }
             } else {
                 float d[8];
-                unpack8(*(const uint4*)(a.da + r * a.ldda + g * 8), d);
+                unpack8(dq, d);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float xh = (z[i] - mu[i]) * rs[i];
@@ -91,6 +91,25 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(RedArgs a) {
                     s0[i] += gr; s1[i] += gr * xh;
                 }
             }
+        };
+        // four rows per trip: all eight 16-byte loads are issued before the first one is consumed (a pure read pass
+        // is bound by the loads in flight per wave); rows are still accumulated in increasing order
+        long long r = r0 + lane_r;
+        for (; r + 3LL * rp < r1; r += 4LL * rp) {
+            uint4 zq[4], dq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                zq[u] = *(const uint4*)(a.z + (r + (long long)u * rp) * a.ldz + g * 8);
+                if (MODE == 1) dq[u] = *(const uint4*)(a.da + (r + (long long)u * rp) * a.ldda + g * 8);
+                else dq[u] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accumulate(zq[u], dq[u]);
+        }
+        for (; r < r1; r += rp) {
+            const uint4 zq = *(const uint4*)(a.z + r * a.ldz + g * 8);
+            const uint4 dq = MODE == 1 ? *(const uint4*)(a.da + r * a.ldda + g * 8) : make_uint4(0, 0, 0, 0);
+            accumulate(zq, dq);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -379,7 +398,7 @@ inline unsigned act_blocks(long long T, int C) {
 
 int chunks_for(long long T, int* rows_per_chunk) {
     long long chunks = (T + 255) / 256;
-    if (chunks > 1024) chunks = 1024;
+    if (chunks > 2048) chunks = 2048;
     const long long rpc = (T + chunks - 1) / chunks;
     *rows_per_chunk = (int)rpc;
     return (int)((T + rpc - 1) / rpc);
