@@ -67,6 +67,84 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
     partial[(long long)blockIdx.y * cols + c] = s;
 }
 
+// vector forms of the two column-sum kernels (cols % 8 == 0 resp. % 4 == 0, 16-byte aligned rows): a workgroup covers
+// 256 columns x rows_per_block rows as (column groups) x (row lanes); every thread issues all of its row loads before the
+// first add (a read pass lives on its loads in flight), row lanes are combined through LDS in lane order: deterministic.
+__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const uint16_t* __restrict__ x, int rows, int cols, long long ld,
+                                                              float* __restrict__ partial, int rows_per_block) {
+    __shared__ float red[8][256];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;             // 32 groups of 8 columns x 8 row lanes
+    const int c = blockIdx.x * 256 + cg * 8;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < cols) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+            uint4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * 8;
+                q[u] = rr < r1 ? *(const uint4*)(x + (long long)rr * ld + c) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s[2 * i] += bf16_to_f32((uint16_t)(w[i] & 0xffff));
+                    s[2 * i + 1] += bf16_to_f32((uint16_t)(w[i] >> 16));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[rl][cg * 8 + i] = s[i];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < cols) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) t += red[l][threadIdx.x];
+        partial[(long long)blockIdx.y * cols + cc] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_colsum_vec_kernel(const float* __restrict__ x, int rows, int cols,
+                                                              uint16_t* __restrict__ y, float* __restrict__ partial,
+                                                              int rows_per_block) {
+    __shared__ float red[4][256];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;             // 64 groups of 4 columns x 4 row lanes
+    const int c = blockIdx.x * 256 + cg * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s[4] = {0, 0, 0, 0};
+    if (c < cols) {
+        for (int r = r0 + rl; r < r1; r += 16) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * 4;
+                q[u] = rr < r1 ? *(const float4*)(x + (long long)rr * cols + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * 4;
+                s[0] += q[u].x; s[1] += q[u].y; s[2] += q[u].z; s[3] += q[u].w;
+                if (y && rr < r1)
+                    *(uint2*)(y + (long long)rr * cols + c) = make_uint2(pack_bf16x2(q[u].x, q[u].y), pack_bf16x2(q[u].z, q[u].w));
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[rl][cg * 4 + i] = s[i];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (partial && cc < cols) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int l = 1; l < 4; ++l) t += red[l][threadIdx.x];
+        partial[(long long)blockIdx.y * cols + cc] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int parts, int cols,
                                                           float* __restrict__ out, int accumulate,
                                                           float* __restrict__ out2 = nullptr, int split = 0) {
@@ -326,8 +404,12 @@ extern "C" int yv_cast_colsum(const float* x, int rows, int cols, void* y_bf16, 
     if (!x || rows <= 0 || cols <= 0 || (colsum && !ws)) return YV_ERR_ARG;
     const int parts = (rows + CS_ROWS - 1) / CS_ROWS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(cast_colsum_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, x, rows, cols,
-                       (uint16_t*)y_bf16, colsum ? ws : nullptr, CS_ROWS);
+    if (!(cols & 3) && !((uintptr_t)x & 15) && !((uintptr_t)y_bf16 & 7))
+        hipLaunchKernelGGL(cast_colsum_vec_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, x, rows, cols,
+                           (uint16_t*)y_bf16, colsum ? ws : nullptr, CS_ROWS);
+    else
+        hipLaunchKernelGGL(cast_colsum_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, x, rows, cols,
+                           (uint16_t*)y_bf16, colsum ? ws : nullptr, CS_ROWS);
     if (colsum)
         launch_reduce_rows(st, ws, parts, cols, colsum, accumulate);
     return yv_launch_status();
@@ -338,8 +420,12 @@ extern "C" int yv_colsum_bf16(const void* x, int rows, int cols, long long ld, f
     if (!x || !colsum || !ws || rows <= 0 || cols <= 0) return YV_ERR_ARG;
     const int parts = (rows + CS_ROWS - 1) / CS_ROWS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, (const uint16_t*)x, rows,
-                       cols, ld, ws, CS_ROWS);
+    if (!(cols & 7) && !(ld & 7) && !((uintptr_t)x & 15))
+        hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, (const uint16_t*)x, rows,
+                           cols, ld, ws, CS_ROWS);
+    else
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols + 255) / 256, parts), dim3(256), 0, st, (const uint16_t*)x, rows,
+                           cols, ld, ws, CS_ROWS);
     launch_reduce_rows(st, ws, parts, cols, colsum, accumulate);
     return yv_launch_status();
 }
