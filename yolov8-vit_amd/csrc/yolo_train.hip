@@ -245,18 +245,20 @@ __global__ __launch_bounds__(256) void bn_act_kernel(ActArgs a) {
 // mode 0 copy, 1 add (dst += src), 2 nearest-2x up (dst (B,2H,2W) <- src (B,H,W)), 3 adjoint of 2 accumulated
 // (dst (B,H,W) += sum of the 2x2 block of src (B,2H,2W)), 4 zero insertion (dst (B,2H,2W): [2y][2x] = src[y][x], else 0),
 // 5 zero fill of dst (B,H,W)
+template <typename IDX>                                   // uint32_t whenever the element count fits: 32-bit divisions
 __global__ __launch_bounds__(256) void view_op_kernel(int mode, const uint16_t* __restrict__ src, long long lds_,
                                                       uint16_t* __restrict__ dst, long long ldd, int B, int H, int W, int C) {
-    const int cg = C >> 3;
+    const IDX cg = (IDX)(C >> 3);
     const int DH = (mode == 2 || mode == 4) ? 2 * H : H, DW = (mode == 2 || mode == 4) ? 2 * W : W;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)B * DH * DW * cg;
+    const IDX idx = (IDX)blockIdx.x * 256 + threadIdx.x;
+    const IDX total = (IDX)B * DH * DW * cg;
     if (idx >= total) return;
     const int g = (int)(idx % cg);
-    const long long p = idx / cg;                      // destination pixel
-    const int x = (int)(p % DW);
-    const long long q = p / DW;
-    const int y = (int)(q % DH), b = (int)(q / DH);
+    const IDX pi = idx / cg;                           // destination pixel
+    const int x = (int)(pi % (IDX)DW);
+    const IDX q = pi / (IDX)DW;
+    const int y = (int)(q % (IDX)DH), b = (int)(q / (IDX)DH);
+    const long long p = (long long)pi;
     uint16_t* d = dst + p * ldd + g * 8;
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (mode == 0) {
@@ -360,23 +362,26 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const uint8_t* __rest
     *(uint4*)(din + p * lddi + g * 8) = pack8(acc);
 }
 
+// IDX = uint32_t whenever the element count allows it: the four divisions per thread are what this write-bound copy
+// spends its instructions on, and 64-bit division is several times the cost of 32-bit
+template <typename IDX>
 __global__ __launch_bounds__(256) void im2col3_kernel(const uint16_t* __restrict__ x, long long ldx, int B, int Hin, int Win,
                                                       int C, int stride, int Hout, int Wout, uint16_t* __restrict__ col) {
-    const int cg = C >> 3;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)B * Hout * Wout * 9 * cg;
+    const IDX cg = (IDX)(C >> 3);
+    const IDX idx = (IDX)blockIdx.x * 256 + threadIdx.x;
+    const IDX total = (IDX)B * Hout * Wout * 9 * cg;
     if (idx >= total) return;
     const int g = (int)(idx % cg);
-    long long t = idx / cg;
+    const IDX t = idx / cg;
     const int tap = (int)(t % 9);
-    const long long row = t / 9;
-    const int ox = (int)(row % Wout);
-    const long long q = row / Wout;
-    const int oy = (int)(q % Hout), b = (int)(q / Hout);
+    const IDX row = t / 9;
+    const int ox = (int)(row % (IDX)Wout);
+    const IDX q = row / (IDX)Wout;
+    const int oy = (int)(q % (IDX)Hout), b = (int)(q / (IDX)Hout);
     const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) v = *(const uint4*)(x + (((long long)b * Hin + iy) * Win + ix) * ldx + g * 8);
-    *(uint4*)(col + row * (9LL * C) + tap * C + g * 8) = v;
+    *(uint4*)(col + (long long)idx * 8) = v;                     // col[row][tap][g*8..] is exactly element idx * 8
 }
 
 __global__ __launch_bounds__(256) void weight_dgrad_kernel(const uint16_t* __restrict__ w, int Cout, int taps, int Cin,
@@ -479,8 +484,13 @@ extern "C" int yv_view_op(int mode, const void* src, long long ld_src, void* dst
     if ((ld_dst & 7) || ld_dst < C || (mode != 5 && ((ld_src & 7) || ld_src < C))) return YV_ERR_ARG;
     if (((uintptr_t)dst & 15) || (src && ((uintptr_t)src & 15))) return YV_ERR_ARG;
     const int up = (mode == 2 || mode == 4) ? 4 : 1;
-    hipLaunchKernelGGL(view_op_kernel, dim3(blocks_for((long long)B * H * W * up * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
-                       mode, (const uint16_t*)src, ld_src, (uint16_t*)dst, ld_dst, B, H, W, C);
+    const long long total = (long long)B * H * W * up * (C >> 3);
+    if (total < (1LL << 31))
+        hipLaunchKernelGGL(view_op_kernel<uint32_t>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mode,
+                           (const uint16_t*)src, ld_src, (uint16_t*)dst, ld_dst, B, H, W, C);
+    else
+        hipLaunchKernelGGL(view_op_kernel<unsigned long long>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mode,
+                           (const uint16_t*)src, ld_src, (uint16_t*)dst, ld_dst, B, H, W, C);
     return yv_launch_status();
 }
 
@@ -502,8 +512,13 @@ extern "C" int yv_im2col3(const void* x, long long ldx, int B, int Hin, int Win,
         return YV_ERR_ARG;
     if (((uintptr_t)x | (uintptr_t)col) & 15) return YV_ERR_ARG;
     const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;       // k 3, pad 1
-    hipLaunchKernelGGL(im2col3_kernel, dim3(blocks_for((long long)B * Hout * Wout * 9 * (C >> 3))), dim3(256), 0,
-                       (hipStream_t)stream, (const uint16_t*)x, ldx, B, Hin, Win, C, stride, Hout, Wout, (uint16_t*)col);
+    const long long total = (long long)B * Hout * Wout * 9 * (C >> 3);
+    if (total < (1LL << 31))
+        hipLaunchKernelGGL(im2col3_kernel<uint32_t>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)x, ldx, B, Hin, Win, C, stride, Hout, Wout, (uint16_t*)col);
+    else
+        hipLaunchKernelGGL(im2col3_kernel<unsigned long long>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)x, ldx, B, Hin, Win, C, stride, Hout, Wout, (uint16_t*)col);
     return yv_launch_status();
 }
 
