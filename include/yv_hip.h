@@ -287,6 +287,14 @@ int yv_linear_nn(const void* A, int lda, const void* Wkn, int ldw, const float* 
  * copies.  Split over T when a workspace is registered for the stream (deterministic). */
 int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, int N, int K, float* dW, int ldw, void* stream);
 
+/* Weight gradient of a 3x3 / stride 1 / pad 1 convolution with no im2col buffer: dW (N, 9*Cin) f32, column
+ * ((dy+1)*3 + dx+1)*Cin + ci.  Operands over the zero-padded pixel grid (B, H+2, W+2), T = that pixel count rounded up to
+ * a multiple of 64: dYp (T, N) bf16, ZERO on the ring and the tail rows; Xp (T, Cin) bf16 DENSE (row stride Cin), zero on
+ * the ring, with pitch + 1 = W + 3 readable rows of finite values before its first and after its last row (tap offsets
+ * reach there, always multiplied by a zero row of dYp).  yv_view_op mode 6 writes both layouts. */
+int yv_wgrad_conv3(const void* dYp, int ldy, const void* Xp, int Cin, int pitch, int T, int N, float* dW, int ldw,
+                   void* stream);
+
 /* out_t[c][r] = in[r][c] (bf16), rows of out_t zero padded up to the next multiple of 64 (ld_out >= that). */
 int yv_transpose_bf16(const void* in, int rows, int cols, long long ld_in, void* out_t, long long ld_out, void* stream);
 
@@ -366,7 +374,8 @@ int yv_bn_act_bwd(const void* da, long long ldda, const void* z, long long ldz, 
 
 /* Element-wise view operations on (B,H,W,C) bf16 views.  mode 0 copy, 1 dst += src, 2 nearest-2x upsample
  * (dst (B,2H,2W) <- src (B,H,W)), 3 its adjoint accumulated (dst (B,H,W) += 2x2 block sums of src (B,2H,2W)),
- * 4 zero insertion (dst (B,2H,2W): [2y][2x] = src[y][x], 0 elsewhere: stride-2 data gradient), 5 zero fill. */
+ * 4 zero insertion (dst (B,2H,2W): [2y][2x] = src[y][x], 0 elsewhere: stride-2 data gradient), 5 zero fill,
+ * 6 zero-ring padding (dst (B,H+2,W+2): interior = src (B,H,W), ring = 0: the operand layout of yv_wgrad_conv3). */
 int yv_view_op(int mode, const void* src, long long ld_src, void* dst, long long ld_dst, int B, int H, int W, int C,
                void* stream);
 

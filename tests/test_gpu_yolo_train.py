@@ -177,6 +177,23 @@ def test_conv_backward(yv, B, Hin, Cin, Cout, k, s):
         xp = torch.zeros(Tp, Cin, dtype=torch.bfloat16, device=DEV); xp[:T] = xd.reshape(T, Cin)
         yv.wgrad(dzd, xp, dw, T=Tp)
     assert torch.equal(dw.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(Cout, taps * Cin))
+    if k == 3 and s == 1:
+        # ---- the same gradient without im2col: operands on the zero-padded pixel grid (yv_wgrad_conv3).  The margins and
+        # the tail rows of the activation hold (finite) junk: they only ever meet zero rows of the padded dz
+        hp = Hin + 2
+        tpad = B * hp * hp
+        tpp, mg = (tpad + 63) // 64 * 64, hp + 1
+        buf = torch.randint(-3, 4, ((tpp + 2 * mg) * Cin,), generator=g).to(torch.bfloat16).to(DEV)
+        xpad = buf[mg * Cin:(mg + tpp) * Cin].view(tpp, Cin)
+        yv.view_op(yv.VIEW_PAD, yv.mview(xd), yv.mview(xpad), B, Hin, Hin)
+        ref_pad = F.pad(nhwc(x), (0, 0, 1, 1, 1, 1)).reshape(tpad, Cin)
+        assert torch.equal(xpad[:tpad].float().cpu(), ref_pad)
+        dzp = torch.full((tpp, Cout), 7.0, dtype=torch.bfloat16, device=DEV)
+        yv.view_op(yv.VIEW_PAD, yv.mview(dzd), yv.mview(dzp), B, Hout, Hout)
+        dzp[tpad:].zero_()
+        dw2 = torch.full((Cout, 9 * Cin), -1.0, device=DEV)
+        yv.wgrad_conv3(dzp, xpad, dw2, tpp, hp)
+        assert torch.equal(dw2.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin))
 
 
 def test_blob_nhwc8(yv):

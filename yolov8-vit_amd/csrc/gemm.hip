@@ -52,6 +52,8 @@ struct GemmArgs {
     const uint16_t* a0;
     const uint16_t* a1;          // second concat source (1x1 conv only) or null
     int lda0, lda1;              // pixel / row stride in elements
+    int seg_len;                 // gemm_tn only: X column k lives at (k / seg_len) * seg_stride + k % seg_len (0: plain)
+    long long seg_stride;
     int c0, c1;                  // channels per source (c0 + c1 = Cin); linear: c0 = K
     int up0, up1;                // nearest-2x upsample flags
     int Hin, Win;                // logical input grid (after upsample)
@@ -1126,7 +1128,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
         int cn = n0 + ch * 8; cn = cn < Nw ? cn : Nw - 8;      // column clamp (results of clamped columns are not stored)
         int ck = k0 + ch * 8; ck = ck < Kw ? ck : Kw - 8;
         ysrc[j] = g.a0 + (long long)row * g.lda0 + cn;
-        xsrc[j] = g.w + (long long)row * g.lda1 + ck;
+        long long xoff = ck;
+        if (g.seg_len) { const int sg = ck / g.seg_len; xoff = (long long)sg * g.seg_stride + (ck - sg * g.seg_len); }
+        xsrc[j] = g.w + (long long)row * g.lda1 + xoff;
     }
     auto issue = [&](int tt, int buf) {
         unsigned char* Yt = smem + buf * (2 * TILE);
@@ -1495,12 +1499,13 @@ extern "C" int yv_linear_nn(const void* A, int lda, const void* Wkn, int ldw, co
     return launch_dma<128, 128, 2, 2, 0, true>(g, (hipStream_t)stream);
 }
 
-extern "C" int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, int N, int K, float* dW, int ldw,
-                        void* stream) {
+static int wgrad_impl(const void* dY, int ldy, const void* X, int ldx, int T, int N, int K, float* dW, int ldw, int seg_len,
+                      long long seg_stride, void* stream) {
     if (!dY || !X || !dW || T <= 0 || N <= 0 || K <= 0) return YV_ERR_ARG;
     if ((T & 63) || (N & 7) || (K & 7) || (ldy & 7) || (ldx & 7) || (ldw & 3)) return YV_ERR_ARG;
     if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW) & 15) return YV_ERR_ARG;
     GemmArgs g = {};
+    g.seg_len = seg_len; g.seg_stride = seg_stride;
     g.a0 = (const uint16_t*)dY; g.lda0 = ldy; g.w = (const uint16_t*)X; g.lda1 = ldx;
     g.M = N; g.N = K; g.K = T; g.out = dW; g.ldo = ldw; g.flags = YV_EPI_OUT_F32;
     g.tiles_m = (N + 127) / 128; g.tiles_n = (K + 127) / 128;
@@ -1527,6 +1532,25 @@ extern "C" int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, 
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g);
     }
     return yv_launch_status();
+}
+
+extern "C" int yv_wgrad(const void* dY, int ldy, const void* X, int ldx, int T, int N, int K, float* dW, int ldw,
+                        void* stream) {
+    return wgrad_impl(dY, ldy, X, ldx, T, N, K, dW, ldw, 0, 0, stream);
+}
+
+// 3x3 / stride 1 / pad 1 weight gradient without an im2col buffer.  Both operands are laid out over the PADDED pixel grid
+// (B, H+2, W+2): there the tap (dy, dx) of pixel m is pixel m + dy * (W+2) + dx - a constant row offset - and, the
+// activation being dense (row stride Cin), the three dx taps of one dy are 3*Cin CONSECUTIVE elements.  Column
+// k = ((dy+1)*3 + dx+1)*Cin + ci of the virtual (T, 9*Cin) operand therefore sits at
+//   Xp + (m - pitch - 1) * Cin + (k / 3Cin) * pitch * Cin + k % 3Cin,       pitch = W + 2,
+// which is what gemm_tn's segment addressing reads.  dYp must be ZERO on the padding ring and on the tail rows; the
+// activation ring must be zero too, and pitch + 1 readable rows of finite values must surround the activation.
+extern "C" int yv_wgrad_conv3(const void* dYp, int ldy, const void* Xp, int Cin, int pitch, int T, int N, float* dW, int ldw,
+                              void* stream) {
+    if (!Xp || Cin < 8 || (Cin & 7) || pitch < 3) return YV_ERR_ARG;
+    const uint16_t* base = (const uint16_t*)Xp - (long long)(pitch + 1) * Cin;
+    return wgrad_impl(dYp, ldy, base, Cin, T, N, 9 * Cin, dW, ldw, 3 * Cin, (long long)pitch * Cin, stream);
 }
 
 extern "C" int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,

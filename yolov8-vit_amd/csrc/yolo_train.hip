@@ -244,12 +244,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(ActArgs a) {
 // ---- view ops --------------------------------------------------------------------------------------------
 // mode 0 copy, 1 add (dst += src), 2 nearest-2x up (dst (B,2H,2W) <- src (B,H,W)), 3 adjoint of 2 accumulated
 // (dst (B,H,W) += sum of the 2x2 block of src (B,2H,2W)), 4 zero insertion (dst (B,2H,2W): [2y][2x] = src[y][x], else 0),
-// 5 zero fill of dst (B,H,W)
+// 5 zero fill of dst (B,H,W), 6 zero-ring padding (dst (B,H+2,W+2): interior = src (B,H,W), ring = 0)
 template <typename IDX>                                   // uint32_t whenever the element count fits: 32-bit divisions
 __global__ __launch_bounds__(256) void view_op_kernel(int mode, const uint16_t* __restrict__ src, long long lds_,
                                                       uint16_t* __restrict__ dst, long long ldd, int B, int H, int W, int C) {
     const IDX cg = (IDX)(C >> 3);
-    const int DH = (mode == 2 || mode == 4) ? 2 * H : H, DW = (mode == 2 || mode == 4) ? 2 * W : W;
+    const int DH = (mode == 2 || mode == 4) ? 2 * H : (mode == 6 ? H + 2 : H), DW = (mode == 2 || mode == 4) ? 2 * W : (mode == 6 ? W + 2 : W);
     const IDX idx = (IDX)blockIdx.x * 256 + threadIdx.x;
     const IDX total = (IDX)B * DH * DW * cg;
     if (idx >= total) return;
@@ -284,6 +284,11 @@ __global__ __launch_bounds__(256) void view_op_kernel(int mode, const uint16_t* 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] += s[i];
             }
+    } else if (mode == 6) {
+        if (y >= 1 && y <= H && x >= 1 && x <= W) {
+            *(uint4*)d = *(const uint4*)(src + (((long long)b * H + (y - 1)) * W + (x - 1)) * lds_ + g * 8);
+            return;
+        }
     } else if (mode == 4) {
         if (!(y & 1) && !(x & 1)) {
             *(uint4*)d = *(const uint4*)(src + (((long long)b * H + (y >> 1)) * W + (x >> 1)) * lds_ + g * 8);
@@ -480,11 +485,11 @@ extern "C" int yv_bn_act_bwd(const void* da, long long ldda, const void* z, long
 
 extern "C" int yv_view_op(int mode, const void* src, long long ld_src, void* dst, long long ld_dst, int B, int H, int W, int C,
                           void* stream) {
-    if (mode < 0 || mode > 5 || !dst || (mode != 5 && !src) || B <= 0 || H <= 0 || W <= 0 || C < 8 || (C & 7)) return YV_ERR_ARG;
+    if (mode < 0 || mode > 6 || !dst || (mode != 5 && !src) || B <= 0 || H <= 0 || W <= 0 || C < 8 || (C & 7)) return YV_ERR_ARG;
     if ((ld_dst & 7) || ld_dst < C || (mode != 5 && ((ld_src & 7) || ld_src < C))) return YV_ERR_ARG;
     if (((uintptr_t)dst & 15) || (src && ((uintptr_t)src & 15))) return YV_ERR_ARG;
     const int up = (mode == 2 || mode == 4) ? 4 : 1;
-    const long long total = (long long)B * H * W * up * (C >> 3);
+    const long long total = mode == 6 ? (long long)B * (H + 2) * (W + 2) * (C >> 3) : (long long)B * H * W * up * (C >> 3);
     if (total < (1LL << 31))
         hipLaunchKernelGGL(view_op_kernel<uint32_t>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mode,
                            (const uint16_t*)src, ld_src, (uint16_t*)dst, ld_dst, B, H, W, C);

@@ -106,6 +106,7 @@ _SIGS = {
     "yv_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "yv_linear_nn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "yv_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "yv_wgrad_conv3": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "yv_transpose_bf16": (_i, [_vp, _i, _i, C.c_longlong, _vp, C.c_longlong, _vp]),
     "yv_cast_weights": (_i, [_vp, _i, _i, _vp, _vp, C.c_longlong, _vp]),
     "yv_colsum_ws_floats": (_sz, [_i, _i]),
@@ -608,6 +609,21 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, T: Optional[int] 
     return dw
 
 
+def wgrad_conv3(dyp: torch.Tensor, xp: torch.Tensor, dw: torch.Tensor, T: int, pitch: int):
+    """dw (N, 9*Cin) f32 = 3x3 / stride 1 weight gradient from operands over the zero-padded pixel grid (view_op VIEW_PAD):
+    dyp (>=T, N) bf16 with zero ring / tail, xp (T, Cin) bf16 DENSE view inside a buffer that has pitch + 1 rows of finite
+    values on both sides (see yv_wgrad_conv3)."""
+    for t_ in (dyp, xp, dw):
+        if not t_.is_cuda or t_.stride(-1) != 1:
+            raise YvError("wgrad_conv3 operands must be device tensors with unit column stride")
+    cin = xp.shape[1]
+    if xp.stride(0) != cin or dw.shape[1] != 9 * cin:
+        raise YvError("wgrad_conv3: xp must be dense (row stride Cin) and dw (N, 9*Cin)")
+    check(lib.yv_wgrad_conv3(_p(dyp), dyp.stride(0), _p(xp), cin, pitch, T, dyp.shape[1], _p(dw), dw.stride(0), _st()),
+          "yv_wgrad_conv3")
+    return dw
+
+
 def linear_nn(a: torch.Tensor, w_kn: torch.Tensor, out: torch.Tensor, flags: int = 0, aux: Optional[torch.Tensor] = None,
               M: Optional[int] = None):
     """out[M,N] = a[M,K] @ w_kn[K,N] (weight read reduction-major: dgrad on the master layout)."""
@@ -620,7 +636,7 @@ def linear_nn(a: torch.Tensor, w_kn: torch.Tensor, out: torch.Tensor, flags: int
 
 
 # ------------------------------------------------------------- detector training (row C4)
-VIEW_COPY, VIEW_ADD, VIEW_UP2, VIEW_UP2_BWD, VIEW_ZERO_INSERT, VIEW_ZERO = 0, 1, 2, 3, 4, 5
+VIEW_COPY, VIEW_ADD, VIEW_UP2, VIEW_UP2_BWD, VIEW_ZERO_INSERT, VIEW_ZERO, VIEW_PAD = 0, 1, 2, 3, 4, 5, 6
 
 
 def blob_nhwc8(images: torch.Tensor, out: torch.Tensor):

@@ -19,10 +19,10 @@ import torch
 
 import math
 
-from . import (OPT_ADAMW, OPT_SGD_NESTEROV, VIEW_ADD, VIEW_COPY, VIEW_UP2, VIEW_UP2_BWD, VIEW_ZERO_INSERT, YvError, axpby,
+from . import (OPT_ADAMW, OPT_SGD_NESTEROV, VIEW_ADD, VIEW_COPY, VIEW_PAD, VIEW_UP2, VIEW_UP2_BWD, VIEW_ZERO_INSERT, YvError, axpby,
                blob_nhwc8, bn_act_bwd, bn_act_fwd, ema_update, optim_step,
                bn_stats, bn_ws_floats, cast_colsum, colsum_ws_floats, conv_view, conv_weight_dgrad, detect_loss,
-               detect_loss_ws_bytes, im2col3, maxpool5_bwd, mview, require_gpu, sgd_step, sppf_pool, view_op, wgrad)
+               detect_loss_ws_bytes, im2col3, maxpool5_bwd, mview, require_gpu, sgd_step, sppf_pool, view_op, wgrad, wgrad_conv3)
 from .engines import LAYER_STRIDE, REG_MAX, _c, yolo_conv_keys, yolo_layers
 
 BN_EPS, BN_MOMENTUM = 1e-3, 0.03
@@ -95,13 +95,14 @@ class YoloTrainer:
     def __init__(self, state: Dict[str, torch.Tensor], scale: str = "n", nc: int = 5, size: int = 640, batch: int = 16,
                  lr: float = 1e-4, momentum: float = 0.937, weight_decay: float = 5e-4, device: str = "cuda:0",
                  optimizer: str = "sgd", ema: bool = False, ema_decay: float = 0.9999, ema_tau: float = 2000.0,
-                 overlap_wgrad: bool = True):
+                 overlap_wgrad: bool = True, implicit_wgrad: bool = True):
         require_gpu()
         if size % 32:
             raise YvError("input size must be a multiple of 32")
         self.scale, self.nc, self.size, self.B, self.dev = scale, nc, size, batch, torch.device(device)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.overlap_wgrad, self.s_w, self._pending = overlap_wgrad, None, []
+        self.implicit_wgrad = implicit_wgrad               # 3x3 / stride 1 weight gradients without an im2col buffer
         if optimizer not in ("sgd", "sgd_nesterov", "adamw"):
             raise YvError("optimizer must be 'sgd', 'sgd_nesterov' or 'adamw'")
         self.optimizer, self.use_ema, self.ema_decay, self.ema_tau = optimizer, ema, ema_decay, ema_tau
@@ -306,7 +307,7 @@ class YoloTrainer:
         self.mean: Dict[str, torch.Tensor] = {}
         self.rstd: Dict[str, torch.Tensor] = {}
         self.geom: Dict[str, Tuple[int, int]] = {}
-        ws_f, wd_n, col_n, zi_n = 0, 0, 0, 0
+        ws_f, wd_n, col_n, zi_n, xp_n, dzp_n = 0, 0, 0, 0, 0, 0
         for b, (hin, hout) in self._block_geometry():
             T = B * hout * hout
             self.geom[b.key] = (hin, hout)
@@ -319,7 +320,12 @@ class YoloTrainer:
                 ws_f = max(ws_f, colsum_ws_floats(T, b.cout))
             self.dz[b.key] = torch.zeros((_r64(T), b.cout), dtype=torch.bfloat16, device=dev)
             wd_n = max(wd_n, b.cout * b.taps * b.cin)
-            if b.k == 3:
+            if b.k == 3 and b.s == 1 and self.implicit_wgrad:
+                hp = hin + 2                                   # operands of yv_wgrad_conv3 live on the zero-padded grid
+                tpp = _r64(B * hp * hp)
+                xp_n = max(xp_n, (tpp + 2 * (hp + 1)) * b.cin)
+                dzp_n = max(dzp_n, tpp * b.cout)
+            elif b.k == 3:
                 col_n = max(col_n, _r64(T) * 9 * b.cin)
             if b.s == 2:
                 zi_n = max(zi_n, B * hin * hin * b.cout)
@@ -327,6 +333,8 @@ class YoloTrainer:
         self.wd_buf = torch.zeros(max(wd_n, 8), dtype=torch.bfloat16, device=dev)
         self.col = torch.zeros(max(col_n, 8), dtype=torch.bfloat16, device=dev)
         self.zi = torch.zeros(max(zi_n, 8), dtype=torch.bfloat16, device=dev)
+        self.xp = torch.zeros(max(xp_n, 8), dtype=torch.bfloat16, device=dev)       # zero-initialised: its margins are read
+        self.dzp = torch.zeros(max(dzp_n, 8), dtype=torch.bfloat16, device=dev)
 
     def _block_geometry(self):
         S = self.size
@@ -394,6 +402,19 @@ class YoloTrainer:
         dw = self.gr(b.w).view(b.cout, b.taps * b.cin)
         if b.k == 1:
             wgrad(dz, x_buf[:, x_off:x_off + b.cin], dw, T=Tp)
+        elif b.s == 1 and self.implicit_wgrad:
+            # no im2col: both operands are copied once onto the zero-padded pixel grid, where every tap is a constant row
+            # offset and the three taps of a kernel row are contiguous (yv_wgrad_conv3)
+            hp = hin + 2
+            tpad = self.B * hp * hp
+            tpp, mg = _r64(tpad), hp + 1
+            xp = self.xp[mg * b.cin:(mg + tpp) * b.cin].view(tpp, b.cin)
+            view_op(VIEW_PAD, mview(x_buf, x_off, b.cin), mview(xp), self.B, hin, hin)
+            dzp = self.dzp[:tpp * b.cout].view(tpp, b.cout)
+            view_op(VIEW_PAD, mview(dz), mview(dzp), self.B, hout, hout)
+            if tpp != tpad:
+                dzp[tpad:].zero_()
+            wgrad_conv3(dzp, xp, dw, tpp, hp)
         else:
             col = self.col[:Tp * 9 * b.cin].view(Tp, 9 * b.cin)
             if Tp != T:
