@@ -154,11 +154,23 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     const int cg = threadIdx.x & 7, grp = threadIdx.x >> 3;
     const int c = blockIdx.x * 32 + cg * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < cols)
-        for (int p = grp; p < parts; p += 32) {
+    if (c < cols) {
+        int p = grp;
+        for (; p + 96 < parts; p += 128) {                       // four partial rows per trip, loads first; order unchanged
+            const float4 v0 = *(const float4*)(partial + (long long)p * cols + c);
+            const float4 v1 = *(const float4*)(partial + (long long)(p + 32) * cols + c);
+            const float4 v2 = *(const float4*)(partial + (long long)(p + 64) * cols + c);
+            const float4 v3 = *(const float4*)(partial + (long long)(p + 96) * cols + c);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; p < parts; p += 32) {
             const float4 v = *(const float4*)(partial + (long long)p * cols + c);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    }
     red[grp][cg] = s;
     __syncthreads();
     if (grp == 0 && c < cols) {
