@@ -15,14 +15,28 @@ for name, m, n, k, flags in shapes:
     a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(dev)
     w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
     bias = torch.randn(n, generator=g).to(dev)
+    pad = int(os.environ.get("FB_PAD", "0"))                  # row-stride padding in bytes (channel-camping experiment)
     aq, asc = yvhip.quant_mxfp8(a)
+    if pad:                                                    # strided copies, passed to the C ABI directly
+        a_p = torch.zeros(m, k + pad // 2, dtype=a.dtype, device=dev); a_p[:, :k] = a
+        aq_p = torch.zeros(m, k + pad, dtype=torch.uint8, device=dev); aq_p[:, :k] = aq
     wq, wsc = yvhip.quant_mxfp8(w)
     out = torch.zeros(m, n, dtype=torch.float32 if flags & yvhip.EPI_RES_F32 else torch.bfloat16, device=dev)
     res = {"bf16": [], "mxfp8": [], "quant_a": []}
     for rd in range(5):
         for key in res:
-            fn = {"bf16": lambda: yvhip.linear(a, w, bias, out, flags=flags),
-                  "mxfp8": lambda: yvhip.linear_mxfp8(aq, asc, wq, wsc, bias, out, flags=flags),
+            P = yvhip._p
+            if pad:
+                fb = lambda: yvhip.check(yvhip.lib.yv_linear(P(a_p), a_p.stride(0), P(w), P(bias), m, n, k, P(out), out.stride(0), None, 0,
+                                                              flags | yvhip.EPI_BIAS, None, 1, yvhip._st()), "yv_linear")
+                fm = lambda: yvhip.check(yvhip.lib.yv_linear_mxfp8(P(aq_p), aq_p.stride(0), P(asc), asc.shape[1], P(wq), P(wsc), wsc.shape[1],
+                                                                    P(bias), m, n, k, P(out), out.stride(0), flags | yvhip.EPI_BIAS, None, 1,
+                                                                    yvhip._st()), "yv_linear_mxfp8")
+            else:
+                fb = lambda: yvhip.linear(a, w, bias, out, flags=flags)
+                fm = lambda: yvhip.linear_mxfp8(aq, asc, wq, wsc, bias, out, flags=flags)
+            fn = {"bf16": fb,
+                  "mxfp8": fm,
                   "quant_a": lambda: yvhip.quant_mxfp8(a, aq, asc)}[key]
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
