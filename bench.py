@@ -130,6 +130,27 @@ def bench_train_yolo(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def launch_ranks(n: int) -> int:
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the contract of
+    torch.distributed.run), same command line; rank 0 prints the JSON line.  Returns the worst child exit code."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("YV_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not rehearsal:
+        raise SystemExit(f"--gpus {n}: only {have} device(s) visible (YV_BENCH_REHEARSAL=1 maps every rank to cuda:0 over gloo)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,9 +172,19 @@ def main():
                          "train-yolo = YOLOv8s training step (configs[3])")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched HIP yet (importing torch
+        # and counting devices does not initialise it), and the ranks are started as CHILD processes, never by exec.
+        return launch_ranks(args.gpus)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE={os.environ['WORLD_SIZE']}")
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("YV_BENCH_DRY") == "1":        # launcher test (tests/test_dist_cpu.py): report the rank layout, touch no GPU
+        print(json.dumps({"rank": rank, "world": world, "local": local, "gpus": args.gpus}), flush=True)
+        return 0
     # rehearsal of the multi-rank control flow on a ONE-GPU box: YV_BENCH_REHEARSAL=1 maps every rank to cuda:0 and uses
     # gloo (RCCL refuses two ranks on one device); never used by the driver
     rehearsal = os.environ.get("YV_BENCH_REHEARSAL") == "1"
@@ -280,4 +311,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

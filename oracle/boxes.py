@@ -226,3 +226,40 @@ def letterbox_params(h: int, w: int, new_w: int = 640, new_h: int = 640):
     top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
     left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
     return r, (dw, dh), (nw, nh), (top, bottom, left, right)
+
+
+def letterbox_image(img_hwc_u8: np.ndarray, new_w: int = 640, new_h: int = 640, fill: int = 114) -> np.ndarray:
+    """A1 resample (YOLOTensorRT_yolodet_py_解读.md:67-69: `letterbox(bgr, (W, H))` = aspect-preserving resize +
+    constant border).  Parity UNPINNED: the reference resizes with cv2.resize(INTER_LINEAR), whose fixed-point
+    arithmetic is not reproducible without OpenCV (absent).  This build's stated rule, restated here in numpy float32
+    with one rounding per operation (the device kernel is compiled with -ffp-contract=off, so the two agree bit for bit):
+        src = (dst + 0.5) * (src_size / dst_size) - 0.5, clamped to [0, src_size - 1]  (half-pixel centres)
+        v   = (a + (b - a) fx) (1 - fy) + (c + (d - c) fx) fy,  out = floor(v + 0.5)   (round half up)
+    identity when the resized size equals the source size; border value 114."""
+    h, w = img_hwc_u8.shape[:2]
+    _, _, (nw, nh), (top, _, left, _) = letterbox_params(h, w, new_w, new_h)
+    out = np.full((new_h, new_w, 3), fill, dtype=np.uint8)
+    if (nw, nh) == (w, h):
+        out[top:top + nh, left:left + nw] = img_hwc_u8
+        return out
+    f32 = np.float32
+    half = f32(0.5)
+
+    def taps(n_dst, n_src):
+        s = (np.arange(n_dst, dtype=np.float32) + half) * (f32(n_src) / f32(n_dst)) - half
+        s = np.minimum(np.maximum(s, f32(0)), f32(n_src - 1))
+        i0 = s.astype(np.int32)
+        i1 = np.minimum(i0 + 1, n_src - 1)
+        return i0, i1, (s - i0.astype(np.float32)).astype(np.float32)
+
+    x0, x1, fx = taps(nw, w)
+    y0, y1, fy = taps(nh, h)
+    im = img_hwc_u8.astype(np.float32)
+    fx_ = fx[None, :, None]
+    fy_ = fy[:, None, None]
+    a, b = im[y0][:, x0], im[y0][:, x1]
+    c, d = im[y1][:, x0], im[y1][:, x1]
+    v = (a + (b - a) * fx_) * (f32(1) - fy_) + (c + (d - c) * fx_) * fy_
+    res = np.clip(np.floor(v + half), 0, 255).astype(np.uint8)
+    out[top:top + nh, left:left + nw] = res
+    return out

@@ -63,3 +63,30 @@ def test_union_length():
     assert union_length([(0.0, 1.0), (2.0, 3.5)]) == 2.5                       # disjoint
     assert union_length([(2.0, 3.0), (0.0, 2.5), (2.9, 4.0)]) == 4.0           # overlapping, unsorted
     assert union_length([(0.0, 5.0), (1.0, 2.0), (3.0, 4.0)]) == 5.0           # nested
+
+
+def test_bench_gpus_flag_launches_ranks():
+    """`python bench.py --gpus N` without a launcher starts N rank processes itself (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, same command line); YV_BENCH_DRY makes every rank report its layout instead of touching a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YV_BENCH_DRY="1", YV_BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [(d["rank"], d["local"], d["world"], d["gpus"]) for d in lines] == [(0, 0, 3, 3), (1, 1, 3, 3), (2, 2, 3, 3)]
+    # without the rehearsal switch a box with fewer devices refuses instead of silently running one rank
+    env.pop("YV_BENCH_REHEARSAL")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "device(s) visible" in r.stderr
+    # a launcher-provided world size must agree with the flag
+    env.update(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "disagrees" in r.stderr

@@ -257,3 +257,90 @@ def test_train_class_from_xml_directories(tmp_path):
     if any(r["val_acc"] > 0 for r in res.values()):
         sd = torch.load(tmp_path / "out" / "best.pth", map_location="cpu", weights_only=True)
         assert "model.cls_token" in sd and "fc.3.weight" in sd
+
+
+def test_main_from_concurrent_threads(tmp_path):
+    """app.py:50-61,99-100 calls `main()` and the classifier modules from request threads without a lock.  Two threads
+    that hammer `main()` over different image folders with the SAME engine objects (and a third that calls the wrapper
+    module directly) must each get exactly what a single-threaded call returns: engine steps are serialised at the Python
+    boundary (yvhip.guard.StepGuard)."""
+    import threading
+    import utils.utils as uu
+    from YOLOTensorRT.inferdet import main
+    from YOLOTensorRT.models import TRTModule
+    from yvhip import engines
+    S = 128
+    eng = TRTModule("random:n:5:1", torch.device(DEV), size=S)
+    vsd = engines.init_vit_wrapper_state("vit_tiny_test", 5, seed=2)
+    wpath = str(tmp_path / "best.pth")
+    torch.save(vsd, wpath)
+    net = uu.build_model(CFG=_CFG, modelName="vit_tiny_test", pretrained=wpath)
+    net.to(DEV); net.eval()
+    folders = []
+    for t in range(2):
+        d = tmp_path / f"set{t}"
+        d.mkdir()
+        _make_images(d, [(128 + 8 * t, 128), (200, 150 + 16 * t), (97 + t, 131), (160, 160)])
+        folders.append(str(d))
+    g = torch.Generator().manual_seed(3)
+    xs = torch.rand(3, 3, 224, 224, generator=g) * 2 - 1
+    call = lambda f: main(Engine=eng, imgs=f, device=torch.device(DEV), model_list=[net], transform=None, aliyunoss=None)
+    ref = [call(f) for f in folders]
+    ref_logits = net(xs.to(DEV)).cpu()
+    assert sum(len(r["objects"]) for rr in ref for r in rr["output"]) > 0
+    errors = []
+
+    def run_main(i):
+        try:
+            for _ in range(6):
+                got = call(folders[i])
+                if got != ref[i]:
+                    errors.append(("main", i))
+        except Exception as e:                       # noqa: BLE001 - surfaced below
+            errors.append(("main-exc", i, repr(e)))
+
+    def run_module():
+        try:
+            for _ in range(30):
+                if not torch.equal(net(xs.to(DEV)).cpu(), ref_logits):
+                    errors.append(("module",))
+        except Exception as e:                       # noqa: BLE001
+            errors.append(("module-exc", repr(e)))
+
+    ts = [threading.Thread(target=run_main, args=(0,)), threading.Thread(target=run_main, args=(1,)),
+          threading.Thread(target=run_module)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errors, errors[:4]
+    assert eng.engine.guard.entries >= 2 * 6 + 2
+
+
+@pytest.mark.parametrize("w,h,S", [(200, 150, 128), (150, 200, 128), (1920, 1080, 640), (333, 517, 640), (97, 131, 128),
+                                   (640, 480, 640), (64, 48, 640)])
+def test_letterbox_resample_vs_oracle(w, h, S):
+    """Row A1 / N1: the device letterbox (bilinear, half-pixel centres, round half up, border 114) against
+    oracle/boxes.py::letterbox_image on real non-identity geometries - down-scales, up-scales, both orientations.
+    Bit-exact (same f32 operations, no contraction).  The RULE is this build's statement: cv2.resize's fixed-point
+    INTER_LINEAR is not reproducible without OpenCV, so against the reference the resample stays parity-unpinned."""
+    import yvhip
+    from YOLOTensorRT.models.utils import letterbox_geometry
+    g = np.random.default_rng(w * 7 + h)
+    img = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    # smooth + noisy content: gradients exercise the blend, noise the rounding
+    yy, xx = np.mgrid[0:h, 0:w]
+    img[..., 0] = ((xx * 255) // max(w - 1, 1)).astype(np.uint8)
+    img[..., 1] = ((yy * 255) // max(h - 1, 1)).astype(np.uint8)
+    ref = ob.letterbox_image(img, S, S)
+    r, dwdh, (nw, nh), (left, top) = letterbox_geometry(h, w, (S, S))
+    r2, dwdh2, (nw2, nh2), (top2, _, left2, _) = ob.letterbox_params(h, w, S, S)
+    assert (nw, nh, left, top) == (nw2, nh2, left2, top2) and r == r2 and tuple(dwdh) == tuple(dwdh2)
+    # two images of different size share one canvas (the batch path of inferdet.main)
+    canvas = np.zeros((2, h + 5, w + 9, 3), dtype=np.uint8)
+    canvas[0, :h, :w] = img
+    canvas[1, :h, :w] = img[::-1, ::-1]
+    geom = torch.tensor([[w, h, nw, nh, left, top]] * 2, dtype=torch.int32, device=DEV)
+    out = yvhip.letterbox(torch.from_numpy(canvas).to(DEV), geom, S).cpu().numpy()
+    assert np.array_equal(out[0], ref)
+    assert np.array_equal(out[1], ob.letterbox_image(np.ascontiguousarray(img[::-1, ::-1]), S, S))

@@ -17,7 +17,7 @@ def rel_l2(a, b):
 
 
 @pytest.mark.parametrize("name,R", [("vit_tiny_test", 3), ("vit_base_patch16_224", 2), ("vit_tiny8_test", 2),
-                                    ("vit_base_patch8_224", 1)])
+                                    ("vit_base_patch8_224", 1), ("vit_large_patch16_224", 1)])
 def test_vit_engine_vs_oracle(name, R):
     from yvhip import engines
     sd = ov.init_wrapper_state(name, seed=11)
@@ -45,7 +45,8 @@ def test_vit_engine_vs_oracle(name, R):
     assert labels[:R].cpu()[sure].tolist() == ref_logits.argmax(1)[sure].tolist()
 
 
-@pytest.mark.parametrize("scale,nc,size,B", [("n", 5, 128, 2), ("n", 5, 640, 1), ("s", 80, 64, 1), ("m", 80, 64, 1)])
+@pytest.mark.parametrize("scale,nc,size,B", [("n", 5, 128, 2), ("n", 5, 640, 1), ("s", 80, 64, 1), ("m", 80, 64, 1),
+                                             ("s", 80, 640, 1)])
 def test_yolo_engine_vs_oracle(scale, nc, size, B):
     from yvhip import engines
     sd = oy.init_state(scale, nc, seed=7)
@@ -140,6 +141,41 @@ def test_pipelined_runner_with_dropped_results():
         for i, r in enumerate(ref):
             for k in keys:
                 assert torch.equal(keep[i][k], r[k]), (rnd, i, k)
+
+
+def test_pipelined_runner_with_fresh_inputs_dropped_after_submit():
+    """A streaming caller: every batch is a NEW device tensor that the caller drops right after submit().  The runner
+    reads it on the detect / classify / sub streams later, so it must be record_stream-ed there - otherwise the caching
+    allocator hands its block to the next batch's upload while the previous batch's kernels are still queued."""
+    from yvhip import engines
+    from yvhip.pipeline import DetectClassifyPipeline, PipelinedRunner
+    name, S, B = "vit_tiny_test", 128, 4
+    pipe = DetectClassifyPipeline(engines.YoloEngine(engines.init_yolo_state("n", 5, 3, 4.0), "n", 5, S, DEV),
+                                  [engines.VitEngine(engines.init_vit_wrapper_state(name, 5, 4), name, 5, device=DEV)],
+                                  max_crops_per_image=3)
+    g = torch.Generator().manual_seed(41)
+    host = [torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).pin_memory() for _ in range(8)]
+    keys = ("crop_list", "crop_total", "cls_logits", "cls_label")
+    ref = []
+    for im in host:
+        o = pipe(im.to(DEV))
+        torch.cuda.synchronize()
+        ref.append({k: o[k].clone() for k in keys})
+    keep = [{k: torch.empty_like(v) for k, v in r.items()} for r in ref]
+    torch.cuda.synchronize()
+    for split in (False, True):
+        runner = PipelinedRunner(pipe, split_classifier=split)
+        for rnd in range(3):
+            for i, im in enumerate(host):
+                o = runner.submit(im.to(DEV, non_blocking=True))      # temporary: freed as soon as submit returns
+                with torch.cuda.stream(runner.s_cls):
+                    for k in keys:
+                        keep[i][k].copy_(o[k])
+                del o
+            runner.sync()
+            for i, r in enumerate(ref):
+                for k in keys:
+                    assert torch.equal(keep[i][k], r[k]), (split, rnd, i, k)
 
 
 def test_step_is_graph_capturable():

@@ -219,8 +219,10 @@ def _act_nchw(a, t):
     return t[:a.T].float().cpu().view(a.B, a.H, a.W, a.C).permute(0, 3, 1, 2).contiguous()
 
 
-def test_trainer_local_consistency(yv):
-    """Every module of the un-fused YOLOv8n (nc 5, 2 x 160 x 160) checked in isolation: the oracle module
+@pytest.mark.parametrize("scale,nc,S,B", [("n", 5, 160, 2), ("s", 80, 640, 2)])
+def test_trainer_local_consistency(yv, scale, nc, S, B):
+    """Every module of the un-fused YOLOv8 (n: nc 5, 2 x 160 x 160; s: nc 80, 2 x 640 x 640 = the model, class count and
+    resolution of BASELINE.json configs[3]) checked in isolation: the oracle module
     (oracle/yolo_train.py, fp32 math with bf16 storage where the device stores bf16) is run on the DEVICE's input
     activation and back-propagated from the DEVICE's output gradient; outputs, parameter gradients and (summed over
     all consumers of a tensor) input gradients must agree.  Random-init BatchNorm stacks amplify bf16 storage noise
@@ -230,17 +232,17 @@ def test_trainer_local_consistency(yv):
     from oracle import yolo_train as oy
     from oracle.yolo import topology
     from yvhip.yolo_training import YoloTrainer
-    scale, nc, S, B = "n", 5, 160, 2
     sd = _oracle_state(scale, nc, 3)
     g = torch.Generator().manual_seed(11)
     img = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
     tr = YoloTrainer({k: v.clone() for k, v in sd.items()}, scale=scale, nc=nc, size=S, batch=B)
+    ncp = tr.ncp
     outs = tr.forward(img.to(DEV))
     R = []
     for s in range(3):
         T = outs[s][0].shape[0]
         db = bf(torch.randn(T, 64, generator=g)).float()
-        dc = torch.zeros(T, 8); dc[:, :nc] = bf(torch.randn(T, nc, generator=g)).float()
+        dc = torch.zeros(T, ncp); dc[:, :nc] = bf(torch.randn(T, nc, generator=g)).float()
         R.append((db.to(DEV), dc.to(DEV)))
     tr.backward(R)
     torch.cuda.synchronize()
@@ -286,9 +288,9 @@ def test_trainer_local_consistency(yv):
         b, c = oy.run_detect_scale(P, s, f, train=True, emulate_bf16=True)
         h = b.shape[-1]
         out_err[f"det{s}.box"] = rel_l2(outs[s][0].cpu().view(B, h, h, 64).permute(0, 3, 1, 2), b.detach())
-        out_err[f"det{s}.cls"] = rel_l2(outs[s][1].cpu().view(B, h, h, 8).permute(0, 3, 1, 2)[:, :nc], c.detach())
+        out_err[f"det{s}.cls"] = rel_l2(outs[s][1].cpu().view(B, h, h, ncp).permute(0, 3, 1, 2)[:, :nc], c.detach())
         (b * R[s][0].cpu().view(B, h, h, 64).permute(0, 3, 1, 2)).sum().backward(retain_graph=True)
-        (c * R[s][1].cpu().view(B, h, h, 8).permute(0, 3, 1, 2)[:, :nc]).sum().backward()
+        (c * R[s][1].cpu().view(B, h, h, ncp).permute(0, 3, 1, 2)[:, :nc]).sum().backward()
         add(fidx, f.grad)
     for k, v in P.items():
         if v.grad is not None:

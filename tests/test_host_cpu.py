@@ -277,3 +277,46 @@ def test_yolo2dict(tmp_path):
     assert [r[0] for r in res] == ["a.jpg", "b.jpg"]
     assert res[0][1] == [{'name': -1, 'xmin': 0, 'ymin': 0, 'xmax': 1, 'ymax': 1}]
     assert res[1][1] == [{'name': 2, 'xmin': 1, 'ymin': 2, 'xmax': 30, 'ymax': 40}, {'name': 3, 'xmin': 5, 'ymin': 6, 'xmax': 7, 'ymax': 8}]
+
+
+def test_step_guard_serialises_threads_and_orders_streams():
+    """yvhip.guard.StepGuard (the per-engine lock of the Python boundary, app.py:50-61 calls the path from several
+    threads): two threads can never be inside a step at once; re-entry from the holder is allowed (pipeline -> engine);
+    an entrant on a different stream than the previous holder waits for that stream."""
+    import threading
+    import time
+    from yvhip.guard import StepGuard
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name, self.waited = name, []
+
+        def wait_stream(self, other):
+            self.waited.append(other.name)
+
+    cur = threading.local()
+    g = StepGuard(stream_fn=lambda: cur.s)
+    inside, worst, order = [0], [0], []
+
+    def worker(name, stream):
+        cur.s = stream
+        for _ in range(20):
+            with g:
+                with g:                                   # re-entrant
+                    inside[0] += 1
+                    worst[0] = max(worst[0], inside[0])
+                    order.append(name)
+                    time.sleep(0.001)
+                    inside[0] -= 1
+
+    sa, sb = FakeStream("a"), FakeStream("b")
+    ts = [threading.Thread(target=worker, args=("A", sa)), threading.Thread(target=worker, args=("B", sb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert worst[0] == 1 and g.entries == 40
+    # every hand-over between the two streams produced exactly one cross-stream wait on the newcomer's stream
+    switches_to_a = sum(1 for p, q in zip(order, order[1:]) if p == "B" and q == "A")
+    switches_to_b = sum(1 for p, q in zip(order, order[1:]) if p == "A" and q == "B")
+    assert sa.waited == ["b"] * switches_to_a and sb.waited == ["a"] * switches_to_b

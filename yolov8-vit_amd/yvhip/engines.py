@@ -18,6 +18,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
+from .guard import StepGuard
 from . import (EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, attention_mxfp8,
                cls_rows,
                conv2d, detect_decode, layernorm, layernorm_mxfp8, linear, linear_mxfp8, linear_mxfp8_q, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
@@ -153,6 +154,7 @@ class YoloEngine:
             bp[:nc] = self.b[kc]
             self.w[kc + ".pad"], self.b[kc + ".pad"] = wp, bp
         self._bufs: Dict[int, dict] = {}
+        self.guard = StepGuard()                 # one replay of the launch list at a time (callers may be threads)
         self.A = sum((size // s) ** 2 for s in (8, 16, 32))
 
     # -- buffers are allocated once per batch size and reused (no allocation in the step)
@@ -203,7 +205,12 @@ class YoloEngine:
                out, 0, EPI_SILU)
 
     def forward_raw(self, images: torch.Tensor):
-        """Runs backbone+neck+head; returns per-scale (box logits f32, class logits f32) NHWC buffers."""
+        """Runs backbone+neck+head; returns per-scale (box logits f32, class logits f32) NHWC buffers (engine-owned:
+        hold `self.guard` across the call and the consumption of the result when other threads may use the engine)."""
+        with self.guard:
+            return self._forward_raw(images)
+
+    def _forward_raw(self, images: torch.Tensor):
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3:
             raise YvError("images must be (B,S,S,3) uint8")
         B, S = images.shape[0], images.shape[1]
@@ -257,8 +264,9 @@ class YoloEngine:
         return box_l, cls_l
 
     def __call__(self, images: torch.Tensor):
-        box_l, cls_l = self.forward_raw(images)
-        return detect_decode(box_l, cls_l, self.size, self.nc)
+        with self.guard:                         # the decode reads the engine-owned head buffers
+            box_l, cls_l = self._forward_raw(images)
+            return detect_decode(box_l, cls_l, self.size, self.nc)
 
 
 # ------------------------------------------------------------------------------------------ ViT
@@ -359,6 +367,15 @@ class VitEngine:
         if tuple(self.fc2w.shape) != (num_classes, 128):
             raise YvError("fc.3.weight does not match num_classes")
         self._bufs: Dict[tuple, dict] = {}
+        self._guards: Dict[int, StepGuard] = {}
+
+    def guard(self, slot: int = 0) -> StepGuard:
+        """Guard of one buffer set: hold it across backbone() + head() (the features live in engine-owned buffers).
+        Different slots are independent (the split classifier runs two of them concurrently on two streams)."""
+        g = self._guards.get(slot)
+        if g is None:
+            g = self._guards.setdefault(slot, StepGuard())
+        return g
 
     def _buffers(self, cap: int, slot: int = 0) -> dict:
         """Activation buffers for `cap` crops; `slot` selects an independent set (concurrent sub-batches)."""
@@ -385,6 +402,10 @@ class VitEngine:
 
     def backbone(self, patches: torch.Tensor, cap: int, count: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
         """patches (cap*tok, 3*P*P) bf16 -> feats (cap,1024) f32 (columns >= 1000 are zero padding)."""
+        with self.guard(slot):
+            return self._backbone(patches, cap, count, slot)
+
+    def _backbone(self, patches: torch.Tensor, cap: int, count: Optional[torch.Tensor], slot: int) -> torch.Tensor:
         b = self._buffers(cap, slot)
         D, N, tok, H = self.D, self.N, self.tok, self.H
         x, h, qkv, o, gbuf = b["x"], b["h"], b["qkv"], b["o"], b["g"]

@@ -10,6 +10,7 @@ rebuilt lazily when the parameters change (version counters).
 """
 from __future__ import annotations
 
+import threading
 from typing import Dict, Optional
 
 import torch
@@ -17,6 +18,9 @@ import torch.nn as nn
 
 from . import YvError, require_gpu
 from .engines import VitEngine, vit_cfg
+
+
+_ENGINE_BUILD_LOCK = threading.Lock()      # module-level: a lock attribute would break copy / pickling of the nn.Module
 
 
 class _Attn(nn.Module):
@@ -103,16 +107,17 @@ class Network_Wrapper(nn.Module):
     def engine(self) -> VitEngine:
         if not isinstance(self.model, ViTBackbone):
             raise YvError("Network_Wrapper.model must come from yvhip.modules.create_model (timm is not used)")
-        key = self._state_key()
-        if self._engine is None or key != self._engine_key:
-            require_gpu()
-            dev = next(self.parameters()).device
-            if dev.type != "cuda":
-                dev = torch.device("cuda", torch.cuda.current_device())
-            sd = {k: v.detach() for k, v in self.state_dict().items()}
-            self._engine = VitEngine(sd, self.model.arch, self.num_class, self.model.img, device=str(dev))
-            self._engine_key = key
-        return self._engine
+        with _ENGINE_BUILD_LOCK:                 # concurrent first calls must not build (and then swap) two engines
+            key = self._state_key()
+            if self._engine is None or key != self._engine_key:
+                require_gpu()
+                dev = next(self.parameters()).device
+                if dev.type != "cuda":
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                sd = {k: v.detach() for k, v in self.state_dict().items()}
+                self._engine = VitEngine(sd, self.model.arch, self.num_class, self.model.img, device=str(dev))
+                self._engine_key = key
+            return self._engine
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         eng = self.engine()
@@ -121,10 +126,11 @@ class Network_Wrapper(nn.Module):
         R = x.shape[0]
         x = x.to(eng.dev)
         patches = patchify_bf16(x.float(), eng.P)
-        feats = eng.backbone(patches, R)
         logits = torch.zeros((R, self.num_class), dtype=torch.float32, device=eng.dev)
         labels = torch.zeros((R,), dtype=torch.int32, device=eng.dev)
-        eng.head(feats, R, logits, labels)
+        with eng.guard():                       # request threads may share this module (app.py:50-61): one replay at a time
+            feats = eng.backbone(patches, R)
+            eng.head(feats, R, logits, labels)
         return logits
 
 

@@ -90,12 +90,13 @@ class DetectClassifyPipeline:
             ctx = torch.cuda.stream(st) if st is not None else _Null()
             if st is not None:
                 st.wait_stream(cur)
-            with ctx:
+            with ctx, v0.guard(slot):                     # the patch buffer belongs to ensemble member 0's buffer set
                 patches = crop_resize_norm(src, crop_list[lo:lo + n], cnt, n, v0.img, v0.P, layout=2,
                                            out=v0.patch_buffer(n, slot))
                 for i, v in enumerate(self.vits):
-                    feats = v.backbone(patches, n, cnt, slot)
-                    v.head(feats, n, logits[lo:lo + n], labels[lo:lo + n], scale=w, accumulate=i > 0, count=cnt)
+                    with v.guard(slot):                     # features live in engine-owned buffers until head() has read them
+                        feats = v.backbone(patches, n, cnt, slot)
+                        v.head(feats, n, logits[lo:lo + n], labels[lo:lo + n], scale=w, accumulate=i > 0, count=cnt)
         for _, _, _, _, st in parts:
             if st is not None:
                 cur.wait_stream(st)
@@ -154,6 +155,12 @@ class PipelinedRunner:
     def submit(self, images: torch.Tensor, ratio=None, dwdh=None, img_wh=None, src_images=None) -> dict:
         cur = torch.cuda.current_stream()
         self.s_det.wait_stream(cur)                               # inputs produced on the caller's stream
+        # the caller may drop its input tensors right after submit(): tell the caching allocator which streams still read
+        # them (same hazard as the hand-off tensors below; bench.py reuses one tensor and never hit it)
+        for t in (images, ratio, dwdh, img_wh, src_images):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                for st in [self.s_det, self.s_cls] + list(self.s_sub or []):
+                    t.record_stream(st)
         if len(self._done) > self.run_ahead:
             self.s_det.wait_event(self._done[-1 - self.run_ahead])  # at most `run_ahead` batches ahead of the classifier
         with torch.cuda.stream(self.s_det):
