@@ -27,20 +27,53 @@ import torch  # noqa: E402
 MFMA_PEAK_TFLOPS = 2500.0        # bf16 dense, MI355X_MICROARCH.md chip table
 
 
-def cpu_baseline(yolo_sd, vit_sd, vit_name, crops, budget_s=20.0, max_images=8):
-    """The oracle (CPU restatement, fp32, batch-1 loop) timed on this box's host cores."""
+def _cpu_loop(imgs, yolo_sd, vit_sd, vit_name, crops, budget_s, max_images):
+    """The oracle's batch-1 loop (oracle/pipeline.py::run_image, stage by stage so that each stage can be timed)."""
+    import numpy as np
+    from oracle import boxes as ob, pipeline as op, vit as ov, yolo as oy
+    st = {"detect": 0.0, "nms_post": 0.0, "crop": 0.0, "classify": 0.0}
+    n, t0 = 0, time.perf_counter()
+    while n < max_images and (time.perf_counter() - t0) < budget_s:
+        img = imgs[n]
+        S = img.shape[0]
+        ta = time.perf_counter()
+        boxes, scores = oy.decode(oy.forward_raw(yolo_sd, oy.blob(img[None]), "n", 5), 5, S)
+        tb = time.perf_counter()
+        num, bb, sc, lb = ob.efficient_nms(boxes, scores)
+        dets = op.post_stages(num[0, 0], bb[0], sc[0], lb[0], 1.0, (0.0, 0.0), (S, S), max_crops=crops)
+        tc = time.perf_counter()
+        cr = [ob.crop_resize_normalize(img.numpy(), d["rect"]) for d in dets if d["ok"]]
+        td = time.perf_counter()
+        if cr:
+            ov.wrapper_forward(vit_sd, torch.from_numpy(np.stack(cr)), vit_name).argmax(1)
+        te = time.perf_counter()
+        st["detect"] += tb - ta; st["nms_post"] += tc - tb; st["crop"] += td - tc; st["classify"] += te - td
+        n += 1
+    dt = time.perf_counter() - t0
+    return n, dt, {k: round(v / max(n, 1) * 1e3, 2) for k, v in st.items()}
+
+
+def cpu_baseline(yolo_sd, vit_sd, vit_name, crops, budget_s=12.0, max_images=8):
+    """The oracle (CPU restatement, fp32, batch-1 loop like the reference's per-image loop) timed on this box's host cores:
+    all cores (the headline `value`) and ONE thread, each with per-stage milliseconds."""
     from oracle import pipeline as op
     g = torch.Generator().manual_seed(1234)
     imgs = torch.randint(0, 256, (max_images + 1, 640, 640, 3), generator=g, dtype=torch.uint8)
+    all_cores = torch.get_num_threads()
     with torch.no_grad():
         op.run_image(imgs[0], yolo_sd, [vit_sd], vit_name, max_crops=crops)      # warm-up (page-in, thread pool)
-        n, t0 = 0, time.perf_counter()
-        while n < max_images and (time.perf_counter() - t0) < budget_s:
-            op.run_image(imgs[n + 1], yolo_sd, [vit_sd], vit_name, max_crops=crops)
-            n += 1
-        dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} synthetic 640x640 images, batch-1 fp32 loop, {crops} crops/image, {dt:.1f}s"}
+        n, dt, stages = _cpu_loop(imgs[1:], yolo_sd, vit_sd, vit_name, crops, budget_s, max_images)
+        torch.set_num_threads(1)
+        try:
+            n1, dt1, stages1 = _cpu_loop(imgs[1:], yolo_sd, vit_sd, vit_name, crops, budget_s * 0.7, 3)
+        finally:
+            torch.set_num_threads(all_cores)
+    return {"value": n / dt, "unit": "images/s", "cores": all_cores, "kind": "port",
+            "note": "oracle port; the reference's own CPU path is not runnable here (timm / ultralytics / TensorRT absent)",
+            "sample": f"{n} synthetic 640x640 images, batch-1 fp32 loop, {crops} crops/image, {dt:.1f}s",
+            "ms_per_image_by_stage": stages,
+            "single_thread": {"value": n1 / dt1, "unit": "images/s", "cores": 1,
+                              "sample": f"{n1} images, {dt1:.1f}s", "ms_per_image_by_stage": stages1}}
 
 
 # HIP maps streams round-robin onto GPU_MAX_HW_QUEUES hardware queues (default 4); the schedule below uses 4 streams next to

@@ -2,6 +2,7 @@
 import inspect
 import os
 import random
+import sys
 
 import numpy as np
 import pytest
@@ -104,6 +105,12 @@ def test_star_import_surface():
                  "log", "cv2", "np", "os", "sse", "torch"):
         assert hasattr(uu, name), name
     assert hasattr(uu.cv2, "INTER_NEAREST")
+    # methods app.py calls on the object-store client (app.py:101 getUrl; utils/utils.py:102-131), unconfigured here
+    oss = uu.AliyunOss()
+    for m in ("put_object_from_file", "getUrl", "delete_object"):
+        assert callable(getattr(oss, m)), m
+    assert oss.delete_object("x.jpg") is False and oss.put_object_from_file("x.jpg", "/nonexistent") is False
+    assert oss.getUrl("a/b.jpg") == "https://{}.{}/a/b.jpg".format(oss.bucket_name, oss.endpoint)
     import utils.trainClass as tc
     for name in ("buildInferModel", "retrain", "crop_image", "FocalLoss", "LabelSmoothingCrossEntropy", "build_loss",
                  "cosine_anneal_schedule", "getCorrect", "valid_one_epoch", "train_one_epoch", "build_transforms",
@@ -320,3 +327,28 @@ def test_step_guard_serialises_threads_and_orders_streams():
     switches_to_a = sum(1 for p, q in zip(order, order[1:]) if p == "B" and q == "A")
     switches_to_b = sum(1 for p, q in zip(order, order[1:]) if p == "A" and q == "B")
     assert sa.waited == ["b"] * switches_to_a and sb.waited == ["a"] * switches_to_b
+
+
+def test_download_images_returns_bgr_like_cv2(monkeypatch, tmp_path):
+    """utils/utils.py:12-56 returns cv2.imdecode's array (BGR) when save_flag is False; app.py:71-78 writes it back with
+    cv2.imwrite.  The HTTP fetch is replaced by an in-memory PNG (no network on the box)."""
+    import io
+    import types
+    import utils.utils as uu
+    from PIL import Image
+    rgb = np.zeros((4, 5, 3), np.uint8)
+    rgb[..., 0], rgb[..., 1], rgb[..., 2] = 200, 100, 50
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="PNG")
+
+    class _Resp:
+        content = buf.getvalue()
+
+        def raise_for_status(self):
+            return None
+    fake = types.SimpleNamespace(get=lambda url, timeout=10: _Resp())
+    monkeypatch.setitem(sys.modules, "requests", fake)
+    arr = uu.download_images("http://host/x.png", str(tmp_path), save_flag=False)
+    assert arr.shape == (4, 5, 3) and arr[0, 0].tolist() == [50, 100, 200]
+    path = uu.download_images("http://host/x.png", str(tmp_path), save_flag=True)
+    assert os.path.exists(path) and np.array_equal(np.asarray(Image.open(path).convert("RGB")), rgb)

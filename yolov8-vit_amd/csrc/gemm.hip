@@ -2,7 +2,7 @@
 //   * Linear  out[M,N] = A[M,K] . W[N,K]^T            (timm Attention.qkv/proj, Mlp.fc1/fc2, PatchEmbed, head)
 //   * Conv2d  k in {1,3}, stride {1,2}, NHWC bf16     (ultralytics Conv/C2f/SPPF/Detect)
 // with the whole elementwise tail fused into the epilogue (folded-BN bias, SiLU,
-// exact-erf GELU, f32 residual-stream accumulate, bf16 shortcut add, pos_embed add).
+// erf-form GELU (erfc approximated to 1.5e-7), f32 residual-stream accumulate, bf16 shortcut add, pos_embed add).
 //
 // Tiling (wave = 64 lanes, v_mfma_f32_16x16x32_bf16):
 //   workgroup = 256 threads = 4 waves, output tile BM x BN, K step 64 (128 B per row).
@@ -31,7 +31,6 @@ int g_opt_wgrad_cap = 128;          // token slices of a conv-shaped weight grad
 thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;   // yv_set_launch_timing: next gemm_dma launch
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
 int g_opt_group_m = 8;
-int g_opt_mx_deep = 0;             // MXFP8 GEMM: 4-stage ring, one workgroup per CU (A/B switch "mx_deep")
 int g_opt_staged = 1;
 std::mutex g_ws_mu;
 std::map<void*, std::pair<void*, size_t>> g_ws;   // per-stream split-K workspace (yv_set_workspace)
@@ -89,7 +88,7 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// exact-erf GELU; erfc by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output step):
+// erf-form GELU (timm's nn.GELU, not the tanh form): erfc APPROXIMATED by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output step):
 //   w = 0.5*erfc(|x|/sqrt2) = t*(a1+t*(a2+...))*exp(-x^2/2),  t = 1/(1+p|x|/sqrt2)   (0.5 folded into a_i)
 //   gelu(x) = x*Phi(x) = max(x,0) - |x*w|
 __device__ __forceinline__ float gelu_f(float x) {
@@ -848,136 +847,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx_kernel(MxArgs a) {
     finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
 }
 
-// Deep-pipeline form of gemm_mx_kernel (same tile, same fragment code): ONE workgroup per CU with a ring of NST = 4 LDS
-// stages and three K steps of DMA in flight (99 KB per CU instead of the 66 KB two co-resident 2-stage workgroups keep
-// in flight).  The 2-stage kernel's step time IS the loaded DMA latency (2 x 33 KB per ~4,100 cycles per CU measured), so
-// bytes in flight per CU are what sets its rate.  Every wave issues the same number of DMA instructions per stage
-// (A_INS + W_INS + 1: the scale dwords go as four 256-byte dword DMAs, one per wave), so one counted vmcnt per step
-// covers "my loads of the current stage have landed" for every wave.
-template <int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_mx_deep_kernel(MxArgs a) {
-    const GemmArgs& g = a.g;
-    constexpr int NW = WM * WN, MF = BM / WM / 16, NF = BN / WN / 16, A_BYTES = BM * 128, W_BYTES = BN * 128;
-    constexpr int A_INS = BM / (8 * NW), W_INS = BN / (8 * NW);
-    constexpr int S_BYTES = ((BM + BN + WM * WN * 64 - 1) / (WM * WN * 64)) * (WM * WN * 256);   // scale dwords (+ slack of idle waves)
-    constexpr int STAGE = A_BYTES + W_BYTES + S_BYTES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int M = g.M;
-    if (g.m_dev) { long long md = (long long)g.m_dev[0] * g.m_mul; M = md < M ? (int)md : M; }
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-    }
-    int tm, tn;
-    {
-        const int GM = g.group_m, per = GM * g.tiles_n;
-        const int grp = bid / per, first = grp * GM;
-        const int gsz = (g.tiles_m - first) < GM ? (g.tiles_m - first) : GM;
-        const int in = bid - grp * per;
-        tm = first + in % gsz;
-        tn = in / gsz;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    if (m0 >= M) return;
-    const int lrow = lane >> 3, lch = lane & 7;
-    const uint8_t* a_src[A_INS];
-    const uint8_t* w_src[W_INS];
-#pragma unroll
-    for (int j = 0; j < A_INS; ++j) {
-        const int r = (j * NW + wave) * 8 + lrow;
-        int m = m0 + r; m = m < g.M ? m : g.M - 1;
-        a_src[j] = (const uint8_t*)g.a0 + (long long)m * g.lda0 + ((lch ^ (r & 7)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < W_INS; ++j) {
-        const int r = (j * NW + wave) * 8 + lrow;
-        int n = n0 + r; n = n < g.N ? n : g.N - 1;
-        w_src[j] = (const uint8_t*)g.w + (long long)n * g.K + ((lch ^ (r & 7)) << 4);
-    }
-    // scale DMA: the tile's BM A dwords then its BN W dwords, lane-linear in LDS; each wave fetches (BM + BN) / NW of them
-    // with dword DMAs of 64 lanes (requires (BM + BN) / NW to be a multiple of 64)
-    constexpr int S_PER_WAVE = (BM + BN + NW * 64 - 1) / (NW * 64);
-    const uint8_t* s_src[S_PER_WAVE];
-    long long s_step[S_PER_WAVE];
-#pragma unroll
-    for (int q = 0; q < S_PER_WAVE; ++q) {
-        int dw = (q * NW + wave) * 64 + lane;                      // dword index in the stage's scale block; waves past its
-        dw = dw < BM + BN ? dw : BM + BN - 1;                      // end re-fetch the last dword into slack (uniform vmcnt)
-        s_src[q] = dw < BM ? a.sa + ((long long)m0 + dw) * 4 : a.sw + ((long long)n0 + (dw - BM)) * 4;
-        s_step[q] = (dw < BM ? a.rows_a : a.rows_w) * 4;
-    }
-    auto issue = [&](int kt, int buf) {
-        unsigned char* A = smem + buf * STAGE;
-        unsigned char* W = A + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < A_INS; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + kt * 128), (lptr_t)(A + (j * NW + wave) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < W_INS; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + kt * 128), (lptr_t)(W + (j * NW + wave) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int q = 0; q < S_PER_WAVE; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(s_src[q] + kt * s_step[q]), (lptr_t)(W + W_BYTES + (q * NW + wave) * 256), 4, 0, 0);
-    };
-    constexpr int PER_STAGE = A_INS + W_INS + S_PER_WAVE;        // DMA instructions one wave issues per stage
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int wrow_m = wm * (BM / WM), wrow_n = wn * (BN / WN);
-    const int fr = lane & 15, fq = lane >> 4;
-    f32x4 acc[NF][MF];
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-#pragma unroll
-        for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nk = g.K >> 7;
-    static_assert(NST == 4 && PER_STAGE * 2 <= 63, "ring depth / vmcnt range");
-#pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
-        if (st < nk) issue(st, st);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & (NST - 1);
-        // my loads of stage kt have landed once at most the younger stages' loads are outstanding
-        const int younger = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_STAGE) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // bare s_barrier: __syncthreads() carries a workgroup fence, which the compiler lowers to vmcnt(0) - that would
-        // drain the two younger stages every step.  Here every wave has waited for ITS loads of stage kt (counted vmcnt
-        // above) and has consumed its LDS reads of step kt - 1 (its MFMAs needed them) before it arrives.
-        asm volatile("s_barrier" ::: "memory");                     // everyone's stage kt is in LDS; everyone is done with kt - 1
-        if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) & (NST - 1));      // into the buffer step kt - 1 read
-        const unsigned char* A = smem + cur * STAGE;
-        const unsigned char* W = A + A_BYTES;
-        const unsigned char* S = W + W_BYTES;
-        i32x8 fa[MF], fw[NF];
-        int sca[MF], scw[NF];
-#pragma unroll
-        for (int j = 0; j < MF; ++j) {
-            const int rr = wrow_m + j * 16 + fr;
-            const u32x4 lo = *(const u32x4*)(A + rr * 128 + (((fq) ^ (rr & 7)) << 4));
-            const u32x4 hi = *(const u32x4*)(A + rr * 128 + (((4 + fq) ^ (rr & 7)) << 4));
-            fa[j] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-            sca[j] = (int)(*(const uint32_t*)(S + rr * 4) >> (8 * fq));              // byte 0 = scale of block fq
-        }
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int rr = wrow_n + i * 16 + fr;
-            const u32x4 lo = *(const u32x4*)(W + rr * 128 + (((fq) ^ (rr & 7)) << 4));
-            const u32x4 hi = *(const u32x4*)(W + rr * 128 + (((4 + fq) ^ (rr & 7)) << 4));
-            fw[i] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-            scw[i] = (int)(*(const uint32_t*)(S + BM * 4 + rr * 4) >> (8 * fq));
-        }
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-#pragma unroll
-            for (int j = 0; j < MF; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[i], fa[j], acc[i][j], 0, 0, 0, scw[i], 0, sca[j]);
-    }
-    __syncthreads();                                               // the epilogue stages through the same LDS
-    finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
-}
-
 // one MFMA on caller-provided register images (layout probe used while bringing the MX path up; tests keep it as the
 // executable statement of the operand layout)
 __global__ __launch_bounds__(64) void mx_probe_kernel(const i32x8* __restrict__ a, const i32x8* __restrict__ b,
@@ -1464,15 +1333,11 @@ static int linear_mx_impl(const void* Aq, long long lda, const void* Ascale, lon
     // (a 256 x 128 / 8-wave instance of the same template was measured on the ViT-L shapes: 4-15 % slower than two
     // 128 x 128 workgroups per CU, like its bf16 counterpart, and is not dispatched)
     g.tiles_m = (M + 127) / 128; g.tiles_n = (N + 127) / 128;
-    // A/B switch "mx_deep" (default off): the 4-stage ring with ONE workgroup per CU.  Measured on the ViT-L shapes with
-    // three K steps genuinely in flight (counted vmcnt, bare s_barrier): 800-830 TFLOP/s against 1,110-1,260 for two
-    // co-resident 2-stage workgroups - the second workgroup's MFMAs under the first one's wait are worth more than the
-    // deeper prefetch.  8-wave forms of both (64 x 32 wave tiles) and padded row strides (channel camping) were neutral
-    // or slower; the raw v_mfma_scale issue rate is 4.4 PFLOP/s (tools/mfma_rate.hip), so none of this is MFMA-bound.
-    const bool deep = g_opt_mx_deep == 1 && (K >> 7) >= 4;
+    // (a 4-stage ring with ONE workgroup per CU and three K steps in flight was built in round 1, measured 35 % slower than two
+    // co-resident 2-stage workgroups, and removed in round 2: see DESIGN.md section 6, "MX deep ring")
     const int threads = 256;
-    const size_t lds = (deep ? 4 : 2) * (size_t)(128 * 128 * 2 + 1024);
-    auto kern = deep ? gemm_mx_deep_kernel<128, 128, 2, 2, 4> : gemm_mx_kernel<128, 128, 2, 2>;
+    const size_t lds = 2 * (size_t)(128 * 128 * 2 + 1024);
+    auto kern = gemm_mx_kernel<128, 128, 2, 2>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;
     if (t_time_start || t_time_stop) {
@@ -1496,7 +1361,6 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!strcmp(key, "linear_variant")) { g_opt_variant = value; return YV_OK; }
     if (!strcmp(key, "wgrad_split_cap")) { g_opt_wgrad_cap = value; return YV_OK; }
     if (!strcmp(key, "linear_group_m")) { g_opt_group_m = value; return YV_OK; }
-    if (!strcmp(key, "mx_deep")) { g_opt_mx_deep = value; return YV_OK; }
     if (!strcmp(key, "staged_epilogue")) { g_opt_staged = value; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_splitk")) { g_opt_linear_splitk = value; return YV_OK; }

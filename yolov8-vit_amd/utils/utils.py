@@ -35,8 +35,9 @@ def build_model(CFG, modelName=None, pretrained_path=None, pretrained=None):
 
 
 def download_images(url, save_folder, save_flag=True):
-    """Fetch one image over HTTP (utils/utils.py:12-56).  Returns the saved path, the decoded RGB array
-    when save_flag is False, or False on any failure."""
+    """Fetch one image over HTTP (utils/utils.py:12-56).  Returns the saved path, the decoded array in cv2's BGR
+    channel order when save_flag is False (the reference returns cv2.imdecode's result and app.py:71-78 hands it to
+    cv2.imwrite), or False on any failure."""
     try:
         import io
         import requests
@@ -48,7 +49,7 @@ def download_images(url, save_folder, save_flag=True):
         print(f"Error downloading {url}: {e}")
         return False
     if not save_flag:
-        return np.asarray(img)
+        return np.asarray(img)[..., ::-1].copy()
     name = os.path.basename(url).split("?")[0] or "downloaded_image.jpg"
     os.makedirs(save_folder, exist_ok=True)
     path = os.path.join(save_folder, name)
@@ -67,10 +68,12 @@ class AliyunOss(object):
 
     def __init__(self):
         self.bucket = None
+        self.endpoint = os.environ.get("OSS_ENDPOINT", "")
+        self.bucket_name = os.environ.get("OSS_BUCKET", "")
         try:
             import oss2
             kid, sec = os.environ.get("OSS_ACCESS_KEY_ID"), os.environ.get("OSS_ACCESS_KEY_SECRET")
-            ep, name = os.environ.get("OSS_ENDPOINT"), os.environ.get("OSS_BUCKET")
+            ep, name = self.endpoint, self.bucket_name
             if kid and sec and ep and name:
                 self.bucket = oss2.Bucket(oss2.Auth(kid, sec), ep, name)
         except Exception:
@@ -84,6 +87,21 @@ class AliyunOss(object):
             return True
         except Exception as e:
             print(f"oss upload failed: {e}")
+            return False
+
+    def getUrl(self, name):
+        """Public URL of an object (utils/utils.py:114-116; app.py:101 calls it)."""
+        return "https://{}.{}/{}".format(self.bucket_name, self.endpoint, name)
+
+    def delete_object(self, name):
+        """utils/utils.py:119-131: True when deleted, False when missing / failing / unconfigured."""
+        if self.bucket is None:
+            return False
+        try:
+            self.bucket.delete_object(name)
+            return True
+        except Exception as e:
+            print(f"Error deleting object {name} from OSS: {e}")
             return False
 
 
