@@ -37,13 +37,18 @@ def main():
     tr = VitTrainer(sd, name, 5, device="cuda:0", bucket_mb=1.0 if "tiny" in name else 32.0)
     pm = patches[lo * tok:hi * tok].to("cuda:0")
     lb = labels[lo:hi].to("cuda:0")
-    losses = []
+    losses, grads = [], []
     for s in range(steps):
-        loss, _ = tr.step(pm, lb, 0.01)
+        tr.forward(pm, hi - lo)
+        loss = tr.backward(pm, lb, hi - lo)
+        tr.reducer.finish()                       # all-reduced SUM of the two ranks' gradients
+        torch.cuda.synchronize()
+        grads.append({k: (v / world).cpu() for k, v in tr.grad_dict().items()})
+        tr.optimizer_step(0.01)
         losses.append(float(loss[0]))
     torch.cuda.synchronize()
     n_buckets = len(tr.reducer.launched)
-    torch.save({"state": {k: v.cpu() for k, v in tr.state_dict().items()}, "losses": losses, "buckets": n_buckets,
+    torch.save({"state": {k: v.cpu() for k, v in tr.state_dict().items()}, "losses": losses, "buckets": n_buckets, "grads": grads,
                 "span": (lo, hi)}, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -133,8 +133,10 @@ def test_config2_vit_b16_trainer_vs_autograd():
 
 
 # per-tensor gradient gates of the ViT trainer tests (rel-L2 against fp32 autograd); see test_config2_* for the table
-GRAD_TOL = 1e-1
-GRAD_TOL_MEDIAN = 5e-2
+# measured on MI355X (round 2): median 0.035, max 0.043 (blocks.9.norm2.weight) - bf16 storage of every activation and
+# activation gradient, not growing with depth; an indexing bug in any tensor shows up as O(1)
+GRAD_TOL = 6e-2
+GRAD_TOL_MEDIAN = 4.5e-2
 
 
 # ------------------------------------------------------------------------------------- configs[4]: YOLOv8m + ViT-L/16

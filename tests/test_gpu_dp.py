@@ -36,9 +36,13 @@ def test_two_rank_step_equals_union_batch_step(tmp_path, name, R, steps):
     sd, patches, labels, tok = make_batch(name, R)
     tr = VitTrainer(sd, name, 5, device="cuda:0")
     pm, lb = patches.to("cuda:0"), labels.to("cuda:0")
-    losses = []
+    losses, grads = [], []
     for _ in range(steps):
-        loss, _ = tr.step(pm, lb, 0.01)
+        tr.forward(pm, R)
+        loss = tr.backward(pm, lb, R)
+        torch.cuda.synchronize()
+        grads.append({k: v.cpu() for k, v in tr.grad_dict().items()})
+        tr.optimizer_step(0.01)
         losses.append(float(loss[0]))
     torch.cuda.synchronize()
     single = {k: v.cpu() for k, v in tr.state_dict().items()}
@@ -47,23 +51,29 @@ def test_two_rank_step_equals_union_batch_step(tmp_path, name, R, steps):
     ranks = [torch.load(o, weights_only=True) for o in outs]
     assert ranks[0]["span"] == (0, R // 2) and ranks[1]["span"] == (R // 2, R)
     assert ranks[0]["buckets"] >= 2                              # the all-reduce really ran bucketed, from inside backward
+    # step 0: the two schedules see identical parameters, so everything must agree to f32 summation order
+    ge = {k: rel_l2(ranks[0]["grads"][0][k], grads[0][k]) for k in sd if float(grads[0][k].abs().max()) > 0}
+    top = sorted(ge.items(), key=lambda kv: -kv[1])[:3]
+    print(f"{name} step 0: mean gradient DP(2) vs union batch, worst: " + ", ".join(f"{k} {e:.1e}" for k, e in top))
+    assert top[0][1] < 1e-5, top                 # measured 1.6e-7 .. 1.9e-7; a wrong 1/world, a missed bucket or a shard mix-up is O(1)
+    assert abs(0.5 * (ranks[0]["losses"][0] + ranks[1]["losses"][0]) - losses[0]) < 1e-5 * max(1.0, abs(losses[0]))
+    for k in sd:                                 # replicas stay bit-identical after the all-reduce + SGD, every step
+        assert torch.equal(ranks[0]["state"][k], ranks[1]["state"][k]), k
+    # later steps: a 3e-8 relative parameter difference (summation order) flips the bf16 rounding of a few hundred of the 86 M
+    # working weights, and a random-init network amplifies that (tests/diagnostics/dp_divergence.py: logits 8.5e-4, gradients
+    # 5.7e-2 at step 1, bit-identical run to run, identical with hand-summed halves and no process group): the schedules
+    # stay statistically equivalent, not bitwise.  Gate: the accumulated parameter update after `steps` steps within 10 %.
     worst = ("", 0.0)
     for k, v0 in sd.items():
-        a, b = ranks[0]["state"][k], ranks[1]["state"][k]
-        assert torch.equal(a, b), k                              # replicas stay bit-identical after the all-reduce
-        d_single = single[k] - v0.float()
-        d_dp = a - v0.float()
+        d_single, d_dp = single[k] - v0.float(), ranks[0]["state"][k] - v0.float()
         if float(d_single.abs().max()) == 0:
             assert float(d_dp.abs().max()) == 0, k
             continue
         e = rel_l2(d_dp, d_single)
         if e > worst[1]:
             worst = (k, e)
-    print(f"{name}: worst parameter-update difference DP(2) vs union batch: {worst[1]:.2e} ({worst[0]})")
-    # the only differences: f32 summation order (token split of the weight gradients changes with the row count, the two
-    # halves are added by the all-reduce) - measured ~1e-6..1e-5; a wrong 1/world, a missed bucket or a shard mix-up is O(1)
-    assert worst[1] < 1e-3, worst
-    # mean of the two half-batch losses = union-batch loss
-    for s in range(steps):
-        m = 0.5 * (ranks[0]["losses"][s] + ranks[1]["losses"][s])
-        assert abs(m - losses[s]) < 1e-4 * max(1.0, abs(losses[s])), (s, m, losses[s])
+    print(f"{name}: worst parameter-update difference after {steps} steps: {worst[1]:.2e} ({worst[0]})")
+    assert worst[1] < 1e-1, worst
+    for s_ in range(steps):
+        m = 0.5 * (ranks[0]["losses"][s_] + ranks[1]["losses"][s_])
+        assert abs(m - losses[s_]) < 2e-2 * max(1.0, abs(losses[s_])), (s_, m, losses[s_])

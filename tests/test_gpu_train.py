@@ -151,7 +151,9 @@ def test_trainer_gradients_vs_autograd(yv, name, R):
     worst = {}
     for k, v in ref.items():
         worst[k] = rel_l2(got[k].cpu(), v)
-    bad = {k: e for k, e in worst.items() if e > 1e-1}
+    ranked = sorted(worst.items(), key=lambda kv: -kv[1])
+    print(f"{name} R={R}: gradient rel-L2 vs fp32 autograd, worst: " + ", ".join(f"{k} {e:.3f}" for k, e in ranked[:4]))
+    bad = {k: e for k, e in worst.items() if e > 8e-2}
     # bf16 forward (logit rel. error ~1e-2) moves dlogits and flips a few ReLU masks of the 1000-d head: the
     # gradient error is a uniform 2-6 % per tensor (tests/diagnostics/grad_error_table.py), not growing with depth
     assert not bad, bad
