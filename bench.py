@@ -163,6 +163,70 @@ def bench_train_yolo(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def bench_postproc(args, dev):
+    """NMS and crop-gather against the HBM roof (north_star: >= 60 % of peak HBM on NMS / crop at batch 256).  Inputs are the
+    SURVEY.md 8(d) synthetic candidate sets (independent of the random-weight detector): per image A = 8400 boxes, centres
+    uniform in [0,640)^2, w,h ~ U[16,256] clipped to the image, scores ~ Beta(0.5,4) (3-5 % above 0.25), nc = 5, seed 4321;
+    crop-gather: 4 crops per image from those boxes.  Algorithmic bytes: NMS 304.8 kB per image (boxes + scores
+    read once + the 2,404-byte result), crop 451,584 B per crop (224*224*3 u8 read + bf16 write).  Each stage is timed with
+    HIP events around `steps` back-to-back launches on the current stream."""
+    import yvhip
+    B, A, nc, S = args.batch, 8400, 5, 640
+    g = torch.Generator().manual_seed(4321)
+    ctr = torch.rand(B, A, 2, generator=g) * S
+    wh = torch.rand(B, A, 2, generator=g) * 240 + 16
+    boxes = torch.cat([(ctr - wh / 2).clamp(0, S), (ctr + wh / 2).clamp(0, S)], -1).contiguous().to(dev)
+    scores = torch.distributions.Beta(0.5, 4.0).sample((B, A, nc)).to(torch.float32)
+    frac = float((scores > 0.25).float().mean())
+    scores = scores.to(dev)
+    images = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).to(dev)
+    R = args.crops
+    cl = torch.zeros(B * R, 6, dtype=torch.int32)
+    for b in range(B):
+        for k in range(R):
+            x0, y0, x1, y1 = [int(v) for v in boxes[b, k].tolist()]
+            cl[b * R + k] = torch.tensor([b, x0, y0, max(x1, x0 + 8), max(y1, y0 + 8), k])
+    cl = cl.to(dev)
+    total = torch.tensor([B * R], dtype=torch.int32, device=dev)
+    out = torch.zeros((B * R * 196, 768), dtype=torch.bfloat16, device=dev)
+
+    def timed(fn):
+        for _ in range(max(args.warmup, 2)):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.steps * 1e3            # us per call
+
+    res = {}
+    res["nms"] = timed(lambda: yvhip.efficient_nms(boxes, scores))
+    res["nms_single_kernel"] = timed(lambda: yvhip.efficient_nms(boxes, scores, single_kernel=True))
+    res["crop"] = timed(lambda: yvhip.crop_resize_norm(images, cl, total, B * R, 224, 16, layout=2, out=out))
+    num = yvhip.efficient_nms(boxes, scores)[0]
+    nms_bytes = B * (A * (16 + 4 * nc) + 2404)
+    crop_bytes = B * R * 451584
+    peak = 8000.0
+    line = {"metric": "NMS + crop-gather HBM throughput (post-processing stages of the hot path)", "unit": "GB/s",
+            "value": nms_bytes / res["nms"] * 1e-3, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "dtype": "f32 boxes / u8 pixels", "data": "synthetic",
+            "config": {"workload": f"EfficientNMS(0.25/0.65/100) on {B} x 8400 x {nc} candidates + {R} crops/image 640->224, "
+                                   "SURVEY 8(d) synthetic sets", "batch": B, "candidates_above_threshold": frac,
+                       "mean_num_dets": float(num.float().mean())},
+            "roofline": {"bound": "hbm", "achieved": nms_bytes / res["nms"] * 1e-3, "peak": peak, "unit": "GB/s",
+                         "frac": nms_bytes / res["nms"] * 1e-3 / peak, "traffic": None,
+                         "kernel": "en2_filter + en2_select + en2_class_small/large + en2_merge (EfficientNMS, per call)",
+                         "us_per_call": res["nms"], "alg_bytes_per_call": nms_bytes},
+            "crop_roofline": {"bound": "hbm", "achieved": crop_bytes / res["crop"] * 1e-3, "peak": peak, "unit": "GB/s",
+                              "frac": crop_bytes / res["crop"] * 1e-3 / peak, "kernel": "crop_kernel<2>",
+                              "us_per_call": res["crop"], "alg_bytes_per_call": crop_bytes},
+            "nms_single_kernel_us": res["nms_single_kernel"]}
+    print(json.dumps(line), flush=True)
+
+
 def launch_ranks(n: int) -> int:
     """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the contract of
     torch.distributed.run), same command line; rank 0 prints the JSON line.  Returns the worst child exit code."""
@@ -200,7 +264,7 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "mxfp8"], default="bf16",
                     help="arithmetic of the classifier's block linears; mxfp8 = OCP e4m3 + E8M0 block scales (configs[4]); the "
                          "headline metric is defined on bf16")
-    ap.add_argument("--mode", choices=["infer", "train", "train-yolo"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "train", "train-yolo", "postproc"], default="infer",
                     help="infer = headline metric (configs[1]); train = ViT-B/16 fine-tune step (configs[2]); "
                          "train-yolo = YOLOv8s training step (configs[3])")
     args = ap.parse_args()
@@ -237,6 +301,8 @@ def main():
     from yvhip import engines
     from yvhip.pipeline import DetectClassifyPipeline, PipelinedRunner
 
+    if args.mode == "postproc":
+        return bench_postproc(args, dev)
     if args.mode == "train":
         return bench_train(args, rank, world, dev, dist)
     if args.mode == "train-yolo":

@@ -104,6 +104,16 @@ int yv_efficient_nms(const float* boxes, const float* scores, int B, int A, int 
                      float iou_threshold, int max_out, int pre_topk, int32_t* num_dets, float* out_boxes,
                      float* out_scores, int32_t* out_labels, void* stream);
 
+/* Same contract (tech.md:41-47, test.ipynb:20-24), multi-workgroup form: the candidate filter streams the scores at
+ * HBM rate over (A*nc / 4096, B) workgroups, per-class greedy NMS runs as (nc, B) workgroups (sort + 64-wide tiles whose
+ * suppression masks are built by ballots), a per-image merge takes the first max_out of the union - bit-identical to
+ * yv_efficient_nms.  `ws`: caller-owned scratch of yv_efficient_nms_ws_bytes() bytes, 256-byte aligned, private to the
+ * call while it is in flight.  This is the form the pipeline uses; the single-kernel form above needs no scratch. */
+size_t yv_efficient_nms_ws_bytes(int B, int A, int nc, int max_out, int pre_topk);
+int yv_efficient_nms_ws(const float* boxes, const float* scores, int B, int A, int nc, float score_threshold,
+                        float iou_threshold, int max_out, int pre_topk, int32_t* num_dets, float* out_boxes,
+                        float* out_scores, int32_t* out_labels, void* ws, size_t ws_bytes, void* stream);
+
 /* det_postprocess + coordinate restore + score filter + int cast
  * (YOLOTensorRT_yolodet_py_解读.md:82-99), then custom_nms dedupe (README.md:41,62-84),
  * then crop_image's integer inflate/clamp (utils/trainClass.py:70-93, eval branch).

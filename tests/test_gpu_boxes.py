@@ -93,29 +93,60 @@ def _rand_dets(B, A, nc, seed, dense=False):
     return boxes, scores
 
 
+@pytest.mark.parametrize("single_kernel", [False, True])
 @pytest.mark.parametrize("B,A,nc,dense", [(3, 500, 5, False), (2, 8400, 5, False), (2, 8400, 5, True), (1, 64, 1, True),
-                                          (2, 1000, 80, False)])
-def test_efficient_nms_vs_oracle(yv, B, A, nc, dense):
+                                          (2, 1000, 80, False), (5, 8400, 1, False), (3, 2100, 3, True)])
+def test_efficient_nms_vs_oracle(yv, B, A, nc, dense, single_kernel):
+    """Both device forms (multi-workgroup = the pipeline's, single workgroup per image) against oracle/boxes.py, bit-exact.
+    Cases: sparse and dense score sets (dense: every score above the threshold -> the top-4096 selection path and classes
+    with thousands of candidates), one class (everything in one greedy chain), 80 classes (mostly empty classes)."""
     boxes, scores = _rand_dets(B, A, nc, 5 + A + nc, dense)
     exp = ob.efficient_nms(boxes, scores)
-    got = yv.efficient_nms(boxes.to(DEV), scores.to(DEV))
+    got = yv.efficient_nms(boxes.to(DEV), scores.to(DEV), single_kernel=single_kernel)
     for e, g in zip(exp, got):
         assert torch.equal(e, g.cpu())
 
 
-def test_efficient_nms_ties_on_cut_and_empty(yv):
+@pytest.mark.parametrize("single_kernel", [False, True])
+def test_efficient_nms_ties_on_cut_and_empty(yv, single_kernel):
     # many equal scores straddling the pre-NMS top-k cut: lowest flat index wins (defined behaviour)
     B, A, nc = 1, 8400, 5
     boxes, _ = _rand_dets(B, A, nc, 77)
     g = torch.Generator().manual_seed(9)
     scores = (torch.randint(0, 6, (B, A, nc), generator=g).float() / 8 + 0.3)
     exp = ob.efficient_nms(boxes, scores)
-    got = yv.efficient_nms(boxes.to(DEV), scores.to(DEV))
+    got = yv.efficient_nms(boxes.to(DEV), scores.to(DEV), single_kernel=single_kernel)
     for e, g_ in zip(exp, got):
         assert torch.equal(e, g_.cpu())
     # nothing above threshold -> zero detections, zero padded
-    got = yv.efficient_nms(boxes.to(DEV), torch.zeros(B, A, nc, device=DEV))
+    got = yv.efficient_nms(boxes.to(DEV), torch.zeros(B, A, nc, device=DEV), single_kernel=single_kernel)
     assert int(got[0][0, 0]) == 0 and float(got[1].abs().sum()) == 0 and float(got[2].abs().sum()) == 0
+
+
+def test_efficient_nms_clustered_boxes_and_small_limits(yv):
+    """Heavy suppression (clusters of near-identical boxes: many tiles are walked before max_out boxes are kept, kept lists
+    of several classes interleave in the merge), small max_out / pre_topk, threshold variations; the two device forms must
+    also agree with each other on a batch of 64 images."""
+    g = torch.Generator().manual_seed(123)
+    B, A, nc = 4, 3000, 4
+    centres = torch.rand(B, 40, 2, generator=g) * 560 + 40
+    pick = torch.randint(0, 40, (B, A), generator=g)
+    c = torch.gather(centres, 1, pick[..., None].expand(B, A, 2)) + torch.randn(B, A, 2, generator=g) * 3
+    wh = 60 + torch.randn(B, A, 2, generator=g).abs() * 6
+    boxes = torch.cat([c - wh / 2, c + wh / 2], -1).contiguous()
+    scores = torch.rand(B, A, nc, generator=g) ** 3
+    for thr, iou, mo, topk in ((0.25, 0.65, 100, 4096), (0.05, 0.5, 7, 300), (0.6, 0.3, 100, 4096), (0.0, 0.65, 100, 1000)):
+        exp = ob.efficient_nms(boxes, scores, thr, iou, mo, topk)
+        for sk in (False, True):
+            got = yv.efficient_nms(boxes.to(DEV), scores.to(DEV), thr, iou, mo, topk, single_kernel=sk)
+            for e, g_ in zip(exp, got):
+                assert torch.equal(e, g_.cpu()), (thr, iou, mo, topk, sk)
+    bb, ss = _rand_dets(64, 8400, 5, 4242)
+    a = yv.efficient_nms(bb.to(DEV), ss.to(DEV))
+    b = yv.efficient_nms(bb.to(DEV), ss.to(DEV), single_kernel=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert int(a[0].sum()) > 0
 
 
 # ------------------------------------------------------------------ postprocess + compaction

@@ -337,6 +337,336 @@ __global__ __launch_bounds__(EN_THREADS) void efficient_nms_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// EfficientNMS contract, multi-workgroup form (round 2).  The single-workgroup kernel above spends ~340 us per image on
+// 32 of 256 CUs; here the work of one image is spread out:
+//   en2_filter   grid (chunks, B)   streams the scores once at HBM rate, compacts the candidates (score > thr) of an
+//                                    image into its list of u64 keys {~orderable(score), flat index}, counts per class
+//   en2_select   grid (B)           ONLY for images with more than pre_topk candidates: exact top-k by (score desc, flat
+//                                    index asc) with the register-resident binary radix select of the kernel above
+//   en2_class    grid (nc, B)       per-class greedy NMS is independent of the other classes: sort the class's candidates,
+//                                    then walk them in tiles of 64 - suppression by earlier kept boxes and the 64 x 64
+//                                    in-tile suppression matrix are computed by all waves in parallel (ballots), the
+//                                    sequential part is a bit-scan over one 64-bit word per tile; stops at max_out kept
+//   en2_merge    grid (B)           merges the per-class kept lists: top max_out by (score desc, flat asc) = exactly
+//                                    what the sequential scan over all classes keeps first, because whether a candidate
+//                                    is kept depends only on higher-ranked candidates of ITS class
+// Same IoU arithmetic, same total order, same outputs bit for bit (tests/test_gpu_boxes.py runs both forms).
+// ---------------------------------------------------------------------------------------------
+constexpr int EN2_FT = 256;                 // filter: threads per workgroup
+constexpr int EN2_FPT = 16;                 // filter: scores per thread  -> 4096 scores per workgroup
+constexpr int EN2_CC_LDS = 2048;            // per-class counters staged in LDS up to this many classes
+
+struct En2Ws {                              // device pointers into the caller's workspace (see yv_efficient_nms_ws_bytes)
+    uint64_t* cand;                         // (B, pre_topk)
+    uint64_t* kept;                         // (B, nc, max_out)
+    uint32_t* count;                        // (B)      candidates of the image (may exceed pre_topk)
+    uint32_t* ccount;                       // (B, nc)  candidates per class (of the selected set)
+    uint32_t* nkept;                        // (B, nc)
+};
+
+__device__ __forceinline__ float key_score(uint32_t key) {          // inverse of desc_key
+    const uint32_t asc = ~key;
+    const uint32_t u = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
+    return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(EN2_FT) void en2_filter_kernel(const float* __restrict__ scores, int total, int nc, float thr,
+                                                            int K, En2Ws ws) {
+    __shared__ uint32_t wave_cnt[EN2_FT / 64];
+    __shared__ uint32_t base_sh;
+    __shared__ uint32_t cc[EN2_CC_LDS];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* S = scores + (size_t)b * total;
+    const int i0 = blockIdx.x * (EN2_FT * EN2_FPT);
+    const bool cc_lds = nc <= EN2_CC_LDS;
+    if (cc_lds) for (int c = tid; c < nc; c += EN2_FT) cc[c] = 0;
+    float v[EN2_FPT];
+#pragma unroll
+    for (int j = 0; j < EN2_FPT; ++j) {                  // all loads in flight; lane-contiguous 256-byte wave accesses
+        const int i = i0 + j * EN2_FT + tid;
+        v[j] = i < total ? S[i] : 0.0f;
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < EN2_FPT; ++j) {
+        const int i = i0 + j * EN2_FT + tid;
+        mine += (i < total && v[j] > thr) ? 1u : 0u;
+    }
+    // exclusive rank of this thread's candidates inside the workgroup
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_cnt[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < EN2_FT / 64; ++w) { const uint32_t c = wave_cnt[w]; if (w < wave) before += c; tot += c; }
+    if (tid == 0) base_sh = tot ? atomicAdd(&ws.count[b], tot) : 0u;
+    __syncthreads();
+    if (tot == 0) return;
+    uint32_t pos = base_sh + before + (incl - mine);
+    uint64_t* list = ws.cand + (size_t)b * K;
+#pragma unroll
+    for (int j = 0; j < EN2_FPT; ++j) {
+        const int i = i0 + j * EN2_FT + tid;
+        if (i < total && v[j] > thr) {
+            if (pos < (uint32_t)K) list[pos] = ((uint64_t)desc_key(v[j]) << 32) | (uint32_t)i;
+            ++pos;
+            const uint32_t c = (uint32_t)i % (uint32_t)nc;
+            if (cc_lds) atomicAdd(&cc[c], 1u); else atomicAdd(&ws.ccount[(size_t)b * nc + c], 1u);
+        }
+    }
+    if (cc_lds) {
+        __syncthreads();
+        for (int c = tid; c < nc; c += EN2_FT) { const uint32_t n = cc[c]; if (n) atomicAdd(&ws.ccount[(size_t)b * nc + c], n); }
+    }
+}
+
+// images with more than K candidates: exact selection of the K best (score desc, flat asc), rewritten into the list
+__global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __restrict__ scores, int A, int nc,
+                                                                float score_thr, int K, En2Ws ws) {
+    __shared__ uint32_t wave_cnt[16];
+    __shared__ uint32_t n_sel_sh, n_eq_sh;
+    __shared__ uint32_t cc[EN2_CC_LDS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (ws.count[b] <= (uint32_t)K) return;
+    const int total = A * nc;
+    const float* S = scores + (size_t)b * total;
+    const int chunks = (total + EN_THREADS - 1) / EN_THREADS;
+    constexpr int EN_CACHE = 48;
+    const bool cached = chunks <= EN_CACHE;
+    uint32_t kreg[EN_CACHE];
+#pragma unroll
+    for (int c = 0; c < EN_CACHE; ++c) {
+        kreg[c] = 0xFFFFFFFFu;
+        const int i = c * EN_THREADS + tid;
+        if (c < chunks && i < total) { const float v = S[i]; if (v > score_thr) kreg[c] = desc_key(v); }
+    }
+    uint32_t prefix = 0, need = (uint32_t)K;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+        uint32_t c0 = 0;
+        if (cached) {
+#pragma unroll
+            for (int c = 0; c < EN_CACHE; ++c) {
+                const uint32_t k = kreg[c];
+                c0 += (k != 0xFFFFFFFFu && ((k & hi_mask) == prefix) && !((k >> bit) & 1u)) ? 1u : 0u;
+            }
+        } else {
+            for (int c = 0; c < chunks; ++c) {
+                const int i = c * EN_THREADS + tid;
+                if (i < total) {
+                    const float v = S[i];
+                    if (v > score_thr) { const uint32_t k = desc_key(v); c0 += (((k & hi_mask) == prefix) && !((k >> bit) & 1u)) ? 1u : 0u; }
+                }
+            }
+        }
+        uint32_t w = c0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) wave_cnt[tid >> 6] = w;
+        __syncthreads();
+        uint32_t t0 = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t0 += wave_cnt[q];
+        if (need > t0) { need -= t0; prefix |= (1u << bit); }
+    }
+    const uint32_t key_star = prefix, need_eq = need;
+    const bool cc_lds = nc <= EN2_CC_LDS;
+    if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) cc[c] = 0;
+    for (int c = tid; c < nc; c += EN_THREADS) ws.ccount[(size_t)b * nc + c] = 0;     // recounted for the selected set
+    if (tid == 0) { n_sel_sh = 0; n_eq_sh = 0; }
+    __syncthreads();
+    __threadfence_block();
+    uint64_t* list = ws.cand + (size_t)b * K;
+    for (int c = 0; c < chunks; ++c) {
+        const int i = c * EN_THREADS + tid;
+        bool pass = false, eq = false;
+        uint32_t k = 0;
+        if (i < total) {
+            const float v = S[i];
+            if (v > score_thr) { k = desc_key(v); pass = k < key_star; eq = k == key_star; }
+        }
+        uint32_t tot;
+        const uint32_t r = block_rank(eq, wave_cnt, &tot);          // ties on the cut score: lowest flat index first
+        const uint32_t base = n_eq_sh;
+        const bool take = pass || (eq && base + r < need_eq);
+        __syncthreads();
+        if (tid == 0) n_eq_sh = base + tot;
+        if (take) {
+            const uint32_t pos = atomicAdd(&n_sel_sh, 1u);
+            if (pos < (uint32_t)K) list[pos] = ((uint64_t)k << 32) | (uint32_t)i;
+            const uint32_t cl = (uint32_t)i % (uint32_t)nc;
+            if (cc_lds) atomicAdd(&cc[cl], 1u); else atomicAdd(&ws.ccount[(size_t)b * nc + cl], 1u);
+        }
+        __syncthreads();
+    }
+    if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) { const uint32_t n = cc[c]; if (n) ws.ccount[(size_t)b * nc + c] = n; }
+}
+
+// per-class greedy NMS over one image's candidate list.  TIER 0: classes with <= 512 candidates (256 threads, 12 KB of LDS,
+// several workgroups per CU); TIER 1: up to 4096 (1024 threads).  Both are launched over the same (nc, B) grid and a
+// workgroup leaves at once when the class belongs to the other tier (the count is only known on the device).
+template <int CAP, int THREADS>
+__device__ __forceinline__ void en2_one_class(unsigned char* smem, const float* __restrict__ boxes, int A, int nc, int c, int b,
+                                              float iou_thr, int max_out, int K, const En2Ws& ws) {
+    constexpr int NW = THREADS / 64;
+    uint64_t* keys = (uint64_t*)smem;                          // CAP
+    float4* sb = (float4*)(keys + CAP);                        // CAP   boxes in sorted order
+    float4* kbox = sb + CAP;                                   // max_out kept boxes
+    uint64_t* Mrow = (uint64_t*)(kbox + max_out);              // 64 in-tile suppression rows
+    uint64_t* dead = Mrow + 64;                                // NW partial masks
+    uint32_t* misc = (uint32_t*)(dead + NW);                   // [0] n_c
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t n_c;
+    uint32_t n = ws.count[b];
+    n = n < (uint32_t)K ? n : (uint32_t)K;
+    const uint64_t* list = ws.cand + (size_t)b * K;
+    if (tid == 0) misc[0] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += THREADS) {
+        const uint64_t k = list[i];
+        if ((uint32_t)k % (uint32_t)nc == (uint32_t)c) {
+            const uint32_t pos = atomicAdd(&misc[0], 1u);
+            if (pos < (uint32_t)CAP) keys[pos] = k;
+        }
+    }
+    __syncthreads();
+    n_c = misc[0] < (uint32_t)CAP ? misc[0] : (uint32_t)CAP;
+    const int np = next_pow2((int)n_c, 64);
+    for (int i = (int)n_c + tid; i < np; i += THREADS) keys[i] = ~0ull;
+    bitonic_sort_u64(keys, np);
+    const float4* Bx = (const float4*)boxes + (size_t)b * A;
+    for (uint32_t i = tid; i < n_c; i += THREADS) sb[i] = Bx[(uint32_t)keys[i] / (uint32_t)nc];
+    __syncthreads();
+
+    uint64_t* out = ws.kept + ((size_t)b * nc + c) * max_out;
+    int nk = 0;
+    for (uint32_t t0 = 0; t0 < n_c && nk < max_out; t0 += 64) {
+        const uint32_t j = t0 + lane;
+        const bool valid = j < n_c;
+        const float4 bj = valid ? sb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float aj = box_area(bj);
+        // (1) suppression by the boxes kept in earlier tiles: the kept list is dealt round-robin to the waves
+        uint64_t d = 0;
+        for (int k = wave; k < nk; k += NW) {
+            const float4 bk = kbox[k];
+            d |= __ballot(valid && iou_f32(bk, box_area(bk), bj, aj) > iou_thr);
+        }
+        if (lane == 0) dead[wave] = d;
+        // (2) in-tile suppression rows: row i = which later members of the tile candidate i would suppress
+        for (int i = wave; i < 64; i += NW) {
+            const uint32_t ji = t0 + i;
+            uint64_t m = 0;
+            if (ji < n_c) {                                     // uniform
+                const float4 bi = sb[ji];
+                m = __ballot(valid && lane > i && iou_f32(bi, box_area(bi), bj, aj) > iou_thr);
+            }
+            if (lane == 0) Mrow[i] = m;
+        }
+        __syncthreads();
+        // (3) the sequential part, one 64-bit word: every wave resolves the tile redundantly (uniform control flow)
+        uint64_t alive = __ballot(valid);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) alive &= ~dead[w];
+        const uint64_t myrow = Mrow[lane];
+        const uint32_t rlo = (uint32_t)myrow, rhi = (uint32_t)(myrow >> 32);
+        uint64_t keptmask = 0;
+        int nk2 = nk;
+        while (alive && nk2 < max_out) {
+            const int i = __builtin_ctzll(alive);
+            keptmask |= 1ull << i;
+            ++nk2;
+            const uint64_t row = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)rlo, i);
+            alive &= ~row;
+            alive &= ~(1ull << i);
+        }
+        if (wave == 0 && ((keptmask >> lane) & 1ull)) {
+            const int r = nk + __builtin_popcountll(keptmask & ((1ull << lane) - 1ull));
+            kbox[r] = bj;
+            out[r] = keys[j];
+        }
+        nk = nk2;
+        __syncthreads();
+    }
+    if (tid == 0) ws.nkept[(size_t)b * nc + c] = (uint32_t)nk;
+    __syncthreads();
+}
+
+// TIER 0: one workgroup per (class, image), classes with 1..512 candidates
+__global__ __launch_bounds__(256) void en2_class_small_kernel(const float* __restrict__ boxes, int A, int nc, float iou_thr,
+                                                              int max_out, int K, En2Ws ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const uint32_t n_c = ws.ccount[(size_t)b * nc + c];
+    if (n_c == 0 || n_c > 512u) return;                        // nkept was zeroed by the memset node of this call
+    en2_one_class<512, 256>(smem, boxes, A, nc, c, b, iou_thr, max_out, K, ws);
+}
+
+// TIER 1: one workgroup per image walks the image's heavy classes (more than 512 candidates: at most K / 512 of them)
+__global__ __launch_bounds__(1024) void en2_class_large_kernel(const float* __restrict__ boxes, int A, int nc, float iou_thr,
+                                                               int max_out, int K, En2Ws ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t heavy[16];
+    __shared__ uint32_t n_heavy;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) n_heavy = 0;
+    __syncthreads();
+    for (int c = tid; c < nc; c += 1024)
+        if (ws.ccount[(size_t)b * nc + c] > 512u) { const uint32_t p = atomicAdd(&n_heavy, 1u); if (p < 16u) heavy[p] = (uint32_t)c; }
+    __syncthreads();
+    const int nh = (int)(n_heavy < 16u ? n_heavy : 16u);
+    for (int h = 0; h < nh; ++h) en2_one_class<EN_MAXK, 1024>(smem, boxes, A, nc, (int)heavy[h], b, iou_thr, max_out, K, ws);
+}
+
+__global__ __launch_bounds__(256) void en2_merge_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                        int A, int nc, int max_out, En2Ws ws, int32_t* __restrict__ num_dets,
+                                                        float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                        int32_t* __restrict__ out_labels) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = (uint64_t*)smem;                          // EN_MAXK
+    __shared__ uint32_t tot_sh;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) tot_sh = 0;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c = wave; c < nc; c += 4) {                       // a wave per class list (order is irrelevant: sorted below)
+        const uint32_t nkc = ws.nkept[(size_t)b * nc + c];
+        if (!nkc) continue;
+        uint32_t off = lane == 0 ? atomicAdd(&tot_sh, nkc) : 0u;
+        off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+        const uint64_t* src = ws.kept + ((size_t)b * nc + c) * max_out;
+        for (uint32_t k = lane; k < nkc; k += 64) if (off + k < (uint32_t)EN_MAXK) keys[off + k] = src[k];
+    }
+    __syncthreads();
+    const int n = (int)(tot_sh < (uint32_t)EN_MAXK ? tot_sh : (uint32_t)EN_MAXK);
+    const int np = next_pow2(n, 64);
+    for (int i = n + tid; i < np; i += 256) keys[i] = ~0ull;
+    bitonic_sort_u64(keys, np);
+    const int nout = n < max_out ? n : max_out;
+    const float4* Bx = (const float4*)boxes + (size_t)b * A;
+    for (int i = tid; i < max_out; i += 256) {
+        const size_t o = (size_t)b * max_out + i;
+        if (i < nout) {
+            const uint32_t flat = (uint32_t)keys[i];
+            ((float4*)out_boxes)[o] = Bx[flat / (uint32_t)nc];
+            out_scores[o] = scores[(size_t)b * A * nc + flat];
+            out_labels[o] = (int32_t)(flat % (uint32_t)nc);
+        } else {
+            ((float4*)out_boxes)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+            out_scores[o] = 0.f;
+            out_labels[o] = 0;
+        }
+    }
+    if (tid == 0) num_dets[b] = nout;
+}
+
+// ---------------------------------------------------------------------------------------------
 // postprocess: restore coords, score filter, dedupe (custom_nms), int cast, inflate.
 // ---------------------------------------------------------------------------------------------
 constexpr int PP_MAX_SLOTS = 1024;
@@ -534,6 +864,60 @@ extern "C" int yv_efficient_nms(const float* boxes, const float* scores, int B, 
         return YV_ERR_LAUNCH;
     hipLaunchKernelGGL(efficient_nms_kernel, dim3(B), dim3(EN_THREADS), lds, (hipStream_t)stream, boxes, scores, A, nc,
                        score_threshold, iou_threshold, max_out, pre_topk, num_dets, out_boxes, out_scores, out_labels);
+    return yv_launch_status();
+}
+
+static size_t en2_layout(int B, int nc, int max_out, int K, En2Ws* w, unsigned char* base, size_t* zero_bytes) {
+    // [count (B) | ccount (B*nc) | nkept (B*nc)] zeroed per call, then cand (B*K u64), kept (B*nc*max_out u64)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_count = take((size_t)B * 4), o_cc = take((size_t)B * nc * 4), o_nk = take((size_t)B * nc * 4);
+    if (zero_bytes) *zero_bytes = off;
+    const size_t o_cand = take((size_t)B * K * 8), o_kept = take((size_t)B * nc * max_out * 8);
+    if (w && base) {
+        w->count = (uint32_t*)(base + o_count); w->ccount = (uint32_t*)(base + o_cc); w->nkept = (uint32_t*)(base + o_nk);
+        w->cand = (uint64_t*)(base + o_cand); w->kept = (uint64_t*)(base + o_kept);
+    }
+    return off;
+}
+
+extern "C" size_t yv_efficient_nms_ws_bytes(int B, int A, int nc, int max_out, int pre_topk) {
+    if (B <= 0 || A <= 0 || nc <= 0 || max_out <= 0 || pre_topk <= 0 || pre_topk > EN_MAXK) return 0;
+    return en2_layout(B, nc, max_out, pre_topk, nullptr, nullptr, nullptr);
+}
+
+extern "C" int yv_efficient_nms_ws(const float* boxes, const float* scores, int B, int A, int nc, float score_threshold,
+                                   float iou_threshold, int max_out, int pre_topk, int32_t* num_dets, float* out_boxes,
+                                   float* out_scores, int32_t* out_labels, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || A <= 0 || nc <= 0 || max_out <= 0 || !boxes || !scores || !num_dets || !out_boxes || !out_scores ||
+        !out_labels)
+        return YV_ERR_ARG;
+    if (B == 0) return YV_OK;
+    if (pre_topk <= 0 || pre_topk > EN_MAXK || nc > 32767 || (long long)A * nc > 0x7fffffffLL || max_out > EN_MAXK)
+        return YV_ERR_LIMIT;
+    if (B > 65535 || nc > 65535) return YV_ERR_LIMIT;            // grid.y / grid.x
+    En2Ws w;
+    size_t zero_bytes = 0;
+    const size_t need = en2_layout(B, nc, max_out, pre_topk, &w, (unsigned char*)ws, &zero_bytes);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) return YV_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, zero_bytes, st) != hipSuccess) return YV_ERR_LAUNCH;
+    const int total = A * nc;
+    const int chunks = (total + EN2_FT * EN2_FPT - 1) / (EN2_FT * EN2_FPT);
+    hipLaunchKernelGGL(en2_filter_kernel, dim3(chunks, B), dim3(EN2_FT), 0, st, scores, total, nc, score_threshold, pre_topk, w);
+    hipLaunchKernelGGL(en2_select_kernel, dim3(B), dim3(EN_THREADS), 0, st, scores, A, nc, score_threshold, pre_topk, w);
+    auto lds_of = [&](int cap, int nw) { return (size_t)cap * (8 + 16) + (size_t)max_out * 16 + 64 * 8 + (size_t)nw * 8 + 16; };
+    const size_t lds0 = lds_of(512, 4), lds1 = lds_of(EN_MAXK, 16);
+    if (hipFuncSetAttribute((const void*)en2_class_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) !=
+        hipSuccess)
+        return YV_ERR_LAUNCH;
+    if (lds0 > 65536 && hipFuncSetAttribute((const void*)en2_class_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds0) != hipSuccess)
+        return YV_ERR_LAUNCH;
+    hipLaunchKernelGGL(en2_class_small_kernel, dim3(nc, B), dim3(256), lds0, st, boxes, A, nc, iou_threshold, max_out, pre_topk, w);
+    hipLaunchKernelGGL(en2_class_large_kernel, dim3(B), dim3(1024), lds1, st, boxes, A, nc, iou_threshold, max_out, pre_topk, w);
+    hipLaunchKernelGGL(en2_merge_kernel, dim3(B), dim3(256), (size_t)EN_MAXK * 8, st, boxes, scores, A, nc, max_out, w, num_dets,
+                       out_boxes, out_scores, out_labels);
     return yv_launch_status();
 }
 

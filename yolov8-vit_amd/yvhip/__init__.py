@@ -65,6 +65,8 @@ _SIGS = {
     "yv_custom_nms_ws_bytes": (_sz, [_i, _i]),
     "yv_custom_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "yv_efficient_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "yv_efficient_nms_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "yv_efficient_nms_ws": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "yv_postprocess_dets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _i, _i,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yv_compact_crops": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -227,8 +229,11 @@ def custom_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float =
 
 
 def efficient_nms(boxes: torch.Tensor, scores: torch.Tensor, score_threshold: float = 0.25,
-                  iou_threshold: float = 0.65, max_output_boxes: int = 100, pre_nms_topk: int = 4096):
-    """boxes (B,A,4), scores (B,A,nc) f32 -> (num_dets (B,1) i32, bboxes (B,K,4), scores (B,K), labels (B,K) i32)."""
+                  iou_threshold: float = 0.65, max_output_boxes: int = 100, pre_nms_topk: int = 4096,
+                  single_kernel: bool = False):
+    """boxes (B,A,4), scores (B,A,nc) f32 -> (num_dets (B,1) i32, bboxes (B,K,4), scores (B,K), labels (B,K) i32).
+    Default: the multi-workgroup form (yv_efficient_nms_ws; scratch from torch's caching allocator, allocated on the current
+    stream like the outputs); single_kernel=True runs the one-workgroup-per-image form.  Both give identical outputs."""
     _chk_dev(boxes, scores)
     B, A, nc = scores.shape
     K = max_output_boxes
@@ -237,8 +242,17 @@ def efficient_nms(boxes: torch.Tensor, scores: torch.Tensor, score_threshold: fl
     ob = torch.empty((B, K, 4), dtype=torch.float32, device=dev)
     osc = torch.empty((B, K), dtype=torch.float32, device=dev)
     ol = torch.empty((B, K), dtype=torch.int32, device=dev)
-    check(lib.yv_efficient_nms(_p(boxes), _p(scores), B, A, nc, float(score_threshold), float(iou_threshold), K,
-                               int(pre_nms_topk), _p(num), _p(ob), _p(osc), _p(ol), _st()), "yv_efficient_nms")
+    if single_kernel:
+        check(lib.yv_efficient_nms(_p(boxes), _p(scores), B, A, nc, float(score_threshold), float(iou_threshold), K,
+                                   int(pre_nms_topk), _p(num), _p(ob), _p(osc), _p(ol), _st()), "yv_efficient_nms")
+        return num, ob, osc, ol
+    wsb = int(lib.yv_efficient_nms_ws_bytes(B, A, nc, K, int(pre_nms_topk)))
+    if B > 0 and wsb == 0:
+        raise YvError("yv_efficient_nms_ws_bytes: arguments out of range")
+    ws = torch.empty((max(wsb, 256),), dtype=torch.uint8, device=dev)
+    check(lib.yv_efficient_nms_ws(_p(boxes), _p(scores), B, A, nc, float(score_threshold), float(iou_threshold), K,
+                                  int(pre_nms_topk), _p(num), _p(ob), _p(osc), _p(ol), _p(ws), wsb, _st()),
+          "yv_efficient_nms_ws")
     return num, ob, osc, ol
 
 
