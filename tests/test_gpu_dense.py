@@ -112,6 +112,86 @@ def test_linear_exact_integer(yv, M, N, K, kind):
     assert torch.equal(part[cut:], x[cut:] if kind == "res" else torch.full((M - cut, N), 3.0))
 
 
+@pytest.mark.parametrize("M,N,K,kind,rows", [
+    (6304, 2304, 768, "plain", 0), (6304, 3072, 768, "gelu", 0), (25216, 2304, 768, "plain", 0), (25216, 3072, 768, "gelu", 256),
+    (2048 + 37, 1536, 128, "plain", 256), (70000, 256, 192, "plain", 0), (12608, 4096, 1024, "gelu", 0), (300, 512, 64 * 5, "plain", 256),
+    (25216, 768, 768, "res", 0), (25216, 768, 3072, "res", 0), (12608, 768, 768, "res", 0), (6304, 2304, 768, "plain", 128),
+    (6304, 768, 768, "res", 160), (6304, 2304, 768, "plain", 192), (6304, 3072, 768, "gelu", 224), (12608, 768, 3072, "res", 224),
+    (5000, 256, 128, "f32", 160), (9999, 512, 192, "res", 128)])
+def test_linear_persistent_8phase_exact_integer(yv, M, N, K, kind, rows):
+    """gemm_p8_kernel (persistent 8-phase kernel: 128..256 x 256 tiles, LDS-DMA stream running across tile boundaries) forced
+    through yv_set_option("linear_variant", 9); `rows` forces the tile height (0 = the host's choice).  Exact integer operands:
+    every wrong offset, stage parity (odd K-tile counts: K = 192, 320), cross-tile prefetch into the wrong tile, ragged last M
+    tile (zeros through the buffer range check), dummy DMA slot of the narrow tiles or slab mix-up is a wrong integer.  Shapes
+    cover 1 .. 5 tiles per workgroup, the minimum K (two K tiles), N = 256 (one tile column), every epilogue (bias -> bf16,
+    bias + GELU -> bf16, bias + f32 residual read-modify-write, plain f32) and the device-side row count."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    a = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    bias = torch.randint(-8, 9, (N,), generator=g).float()
+    lin = a @ w.t() + bias
+    ad, wd, bd = bf(a).to(DEV), bf(w).to(DEV), bias.to(DEV)
+    flags = {"plain": 0, "gelu": yv.EPI_GELU, "res": yv.EPI_RES_F32, "f32": yv.EPI_OUT_F32}[kind]
+    f32 = kind in ("res", "f32")
+    x = torch.randint(-64, 65, (M, N), generator=g).float()
+    yv.set_option("linear_variant", 9)
+    yv.set_option("linear_p8_rows", rows)
+    try:
+        def run(m_dev=None, m_mul=1, with_bias=True):
+            o = x.clone().to(DEV) if f32 else torch.full((M, N), 3.0, dtype=torch.bfloat16, device=DEV)
+            yv.linear(ad, wd, bd if with_bias else None, o, flags=flags, m_dev=m_dev, m_mul=m_mul)
+            torch.cuda.synchronize()
+            return o.cpu().float()
+        got = run()
+        if kind == "plain":
+            assert torch.equal(got, bf(lin).float())
+            assert torch.equal(run(with_bias=False), bf(lin - bias).float())
+        elif kind == "res":
+            assert torch.equal(got, x + lin)
+        elif kind == "f32":
+            assert torch.equal(got, lin)
+        else:
+            # sigmoid-form GELU (max abs error 2.5e-5 against the erf form) + bf16 rounding of the output
+            ref = F.gelu(lin)
+            assert rel_l2(got, ref) < 3e-3
+            assert float((got - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-4
+        md = torch.tensor([M // 3], dtype=torch.int32, device=DEV)
+        part = run(md, 2)
+        cut = 2 * (M // 3)
+        assert torch.equal(part[:cut], got[:cut])
+        assert torch.equal(part[cut:], x[cut:] if f32 else torch.full((M - cut, N), 3.0))
+        # the 128 x 128 kernel must agree on the same data (bit for bit except for the GELU form)
+        yv.set_option("linear_variant", 1)
+        o = x.clone().to(DEV) if f32 else torch.full((M, N), 3.0, dtype=torch.bfloat16, device=DEV)
+        yv.linear(ad, wd, bd, o, flags=flags)
+        if kind != "gelu":
+            assert torch.equal(o.cpu().float(), got)
+    finally:
+        yv.set_option("linear_variant", 1)
+        yv.set_option("linear_p8_rows", 0)
+
+
+def test_gelu_fast_form_accuracy(yv):
+    """The sigmoid-form GELU of the persistent kernel against torch's erf GELU on a dense grid of arguments (identity weight:
+    the GEMM reproduces its bf16 input exactly): abs error <= 2.5e-5 (fit) + half a bf16 step of the output."""
+    N = K = 256
+    M = 2048
+    xs = torch.linspace(-12, 12, M * N).view(M, N)
+    a = bf(xs)
+    w = torch.eye(N)
+    o = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    yv.set_option("linear_variant", 9)
+    try:
+        yv.linear(a.to(DEV), bf(w).to(DEV), None, o, flags=yv.EPI_GELU)
+    finally:
+        yv.set_option("linear_variant", 1)
+    x = a.float()
+    ref = F.gelu(x.double()).float()
+    err = (o.cpu().float() - ref).abs()
+    bound = 3e-5 + ref.abs() * 2.0 ** -8
+    assert bool((err <= bound).all()), float((err - bound).max())
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 

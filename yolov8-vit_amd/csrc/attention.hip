@@ -28,8 +28,13 @@ int g_attn_abl = 0;               // diagnostic builds (yv_attention_debug)
 // optional MXFP8 image of the output (operand of the proj GEMM of yv_linear_mxfp8): e4m3 bytes + E8M0 per 32 columns
 struct AttnMx { uint8_t* q; long long ldq; uint8_t* s; long long rows; };
 
-template <int NT, int ABL = 0>
-__global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __restrict__ qkv, int N, int H, int QB,
+// SINGLE (N <= NP, the ViT-x/16 case: 197 tokens in one 224-row tile): the score block is computed TWICE - pass 1 keeps only
+// the row maximum, pass 2 recomputes each 32-key group, exponentiates it and feeds it to the PV product at once - instead
+// of holding all NT groups (16 f32 registers each) across the softmax.  28 extra MFMAs per wave buy a register budget
+// under 128, i.e. TWO workgroups per CU instead of one (round 1: 194 VGPRs, one 7-wave workgroup per CU, every global ->
+// LDS staging fully exposed).  Same operation order as before: the outputs are bit-identical to the one-pass form.
+template <int NT, int ABL = 0, bool SINGLE = false>
+__global__ __launch_bounds__(NT * 64, SINGLE ? 4 : 1) void attention_kernel(const uint16_t* __restrict__ qkv, int N, int H, int QB,
                                                             float scale_log2e, uint16_t* __restrict__ out,
                                                             const int32_t* __restrict__ r_dev, float* __restrict__ lse, AttnMx mx) {
     // blockIdx.x = ((crop * H + head) * QB + query block); a query block = NT waves x 32 queries = NP rows.
@@ -87,6 +92,70 @@ __global__ __launch_bounds__(NT * 64) void attention_kernel(const uint16_t* __re
         }
         __syncthreads();
         if (ABL == 2) continue;
+
+        if constexpr (SINGLE) {
+            auto scores = [&](int kt) __attribute__((always_inline)) -> f32x16 {
+                f32x16 sv;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sv[e] = 0.f;
+                const int row = kt * 32 + rl;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int c = 2 * ks + hh;
+                    const bf16x8 fk = *(const bf16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                    sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], sv, 0, 0, 0);
+                }
+                if (kt * 32 + 32 > N) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        sv[e] = key < N ? sv[e] : -INFINITY;
+                    }
+                }
+                return sv;
+            };
+            float mx = -INFINITY;
+#pragma unroll 1
+            for (int kt = 0; kt < NT; ++kt) {            // rolled loops: unrolled, the scheduler hoists all NT score blocks again
+                const f32x16 sv = scores(kt);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sv[e]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mb = mx * scale_log2e;
+            float l = 0.f;
+            // the second pass must really recompute: without this the compiler keeps pass 1's score registers alive (CSE)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(fq[ks]));
+#pragma unroll 1
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x16 sv = scores(kt);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    sv[e] = __builtin_amdgcn_exp2f(fmaf(sv[e], scale_log2e, -mb));
+                    l += sv[e];
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 fp;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) fp[j] = (__bf16)sv[8 * st + j];
+                    const int key0 = kt * 32 + 16 * st + 4 * hh;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const unsigned char* vr = Vt + (mt * 32 + rl) * VT_STRIDE + key0 * 2;
+                        const uint2 lo = *(const uint2*)vr;
+                        const uint2 hi = *(const uint2*)(vr + 16);
+                        const u32x4 pk = {lo.x, lo.y, hi.x, hi.y};
+                        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pk), fp, o[mt], 0, 0, 0);
+                    }
+                }
+            }
+            l += __shfl_xor(l, 32, 64);
+            l_run = l;
+            m_run = mx;
+            continue;
+        }
 
         // ---- S^T = K . Q^T ------------------------------------------------------------------
         f32x16 s[NT];
@@ -216,7 +285,9 @@ int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t*
                 hipStream_t st, AttnMx mx) {
     constexpr int NP = NT * 32;
     const size_t lds = (size_t)NP * 128 + 64 * (size_t)(NP * 2 + 8);
-    auto kern = g_attn_abl == 1 ? attention_kernel<NT, 1> : g_attn_abl == 2 ? attention_kernel<NT, 2> : g_attn_abl == 3 ? attention_kernel<NT, 3> : attention_kernel<NT, 0>;
+    const bool single = N <= NP && g_attn_abl != 4;           // ablation 4: the round-1 one-pass form of the single-tile case
+    auto kern = g_attn_abl == 1 ? attention_kernel<NT, 1> : g_attn_abl == 2 ? attention_kernel<NT, 2> : g_attn_abl == 3 ? attention_kernel<NT, 3> :
+                single ? attention_kernel<NT, 0, true> : attention_kernel<NT, 0, false>;
     if (lds > 65536 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;

@@ -19,6 +19,7 @@
 //   blockIdx is remapped so that the 8 XCDs each walk contiguous N tiles of the same
 //   M tile (activation rows stay in that XCD's L2).
 #include <string.h>
+#include <type_traits>
 #include <map>
 #include <mutex>
 #include "yv_common.h"
@@ -32,6 +33,7 @@ thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;   // yv_s
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
 int g_opt_group_m = 8;
 int g_opt_staged = 1;
+int g_opt_p8 = 0;                  // persistent 8-phase 256x256 kernel for wide bf16-output linears (qkv, fc1): "linear_p8"
 std::mutex g_ws_mu;
 std::map<void*, std::pair<void*, size_t>> g_ws;   // per-stream split-K workspace (yv_set_workspace)
 static bool ws_lookup(void* stream, void** ws, size_t* bytes) {
@@ -1077,6 +1079,362 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs g) {
     finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the 8-phase kernel (round 2).  One workgroup per CU walks its tiles; what changes against
+// gemm_8phase_kernel:
+//   * the LDS-DMA stream never drains between tiles: during the last two K tiles of a tile the restage slots load the FIRST two
+//     K tiles of the workgroup's next tile, so the pipeline fill (one HBM/L2 round trip per tile) and the first waits are hidden
+//     behind the epilogue, and the epilogue's stores drain in the shadow of the next main loop instead of in a burst;
+//   * the epilogue does not alias the stage buffers (they are being refilled): every wave transposes 16 output rows at a time
+//     through a private 2 KB slab; the bias vector sits in LDS for the whole launch (a global bias load inside the epilogue
+//     would make hipcc drain the in-flight DMA with vmcnt(0));
+//   * operands are addressed through buffer descriptors (32-bit offsets: half the address registers of flat pointers, which
+//     pays for the second - next tile - offset set; rows past M read as zeros through the range check instead of a clamp);
+//   * GELU by a 9-operation sigmoid form (see gelu_fast_f).
+// LDS map: [stage 0 | stage 1] 2 x 64 KB, 8 slabs x 2 KB, bias 16 KB = 160 KB exactly.
+// Restrictions (checked by the host, everything else takes the 128 x 128 kernel): N % 256 == 0, N <= 4096, K % 64 == 0,
+// bf16 output, flags within {BIAS, GELU}, operand images below 2 GB.
+// ---------------------------------------------------------------------------------------------
+// erf-form GELU through x * sigmoid(x * (p0 + p1 x^2 + p2 x^4)), coefficients fitted (minimax, |x| <= 8) against
+// 0.5 x (1 + erf(x / sqrt 2)): max abs error 2.5e-5 - below half a bf16 step of the output everywhere the output exceeds
+// 0.01 in magnitude.  x^2 is clamped at 64 (beyond |x| = 8 the result is x or 0 to f32 precision; the quartic would turn over).
+__device__ __forceinline__ float gelu_fast_f(float x) {
+    const float x2 = fminf(x * x, 64.0f);
+    float q = fmaf(-7.03039117e-4f * -1.4426950408889634f, x2, 7.40113286e-2f * -1.4426950408889634f);
+    q = fmaf(q, x2, 1.59501573f * -1.4426950408889634f);
+    const float e = __builtin_amdgcn_exp2f(x * q);                  // exp(-z)
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+typedef __attribute__((address_space(3))) void* lds_void_t;
+
+// MF0 / MF1: 16-row activation fragments per wave group in the first / second half of its rows; tile = 32 (MF0 + MF1) rows x
+// 256 columns.  (4,4) = 256 rows is the template of the guide; the smaller instances exist for tile-count quantisation: a
+// persistent grid of 256 workgroups runs ceil(tiles / 256) rounds, and e.g. the 297 tiles of a 25,216 x 768 output cost two
+// rounds at 256 rows but 474 tiles = 1.85 rounds of 160-row tiles (-37 %).  The host picks the instance that minimises
+// rounds x rows.  A-operand DMA slots that a smaller tile does not need are issued with an out-of-range offset (the buffer
+// range check turns them into no-ops) so that every wave keeps issuing the same number of DMA instructions per phase, which
+// is what the counted vmcnt relies on.
+template <int MF0, int MF1, bool F32OUT>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
+    constexpr int MF = MF0 + MF1, NF = 4;
+    constexpr int RG = MF * 16, BM = 2 * RG;                   // rows per wave group / per tile
+    constexpr int A_BYTES = 256 * 128, W_BYTES = 256 * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int SLAB0 = 2 * STAGE, SLAB = 2048, BIAS0 = SLAB0 + 8 * SLAB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int M = g.M;
+    if (g.m_dev) { long long md = (long long)g.m_dev[0] * g.m_mul; M = md < M ? (int)md : M; }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = g.N >> 8;
+    const int ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    // position of this block inside a round of G blocks: XCD x (= blockIdx & 7 under round-robin placement, speed only) walks a
+    // contiguous chunk of the round's tile sequence
+    int bpos;
+    {
+        const int q = G >> 3, r = G & 7, x = blockIdx.x & 7;
+        bpos = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);
+    }
+    if (bpos >= ntiles) return;
+
+    {   // bias -> LDS once (plain loads, before any DMA is in flight)
+        float* bl = (float*)(smem + BIAS0);
+        for (int i = tid; i < g.N; i += 512) bl[i] = (g.flags & YV_EPI_BIAS) ? g.bias[i] : 0.0f;
+    }
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.a0, 0, (int)(((long long)(g.M - 1) * g.lda0 + g.K) * 2), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (int)((long long)g.N * g.K * 2), 0x00020000);
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wrow_m = wm * RG, wrow_n = wn * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int lrow = lane >> 3, lch = lane & 7;
+    auto coords = [&](int seq, int& m0, int& n0) __attribute__((always_inline)) {   // grouped order: GM consecutive M tiles share a W tile
+        const int GM = g.group_m, per = GM * tiles_n;
+        const int grp = seq / per, first = grp * GM;
+        const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
+        const int in = seq - grp * per;
+        m0 = (first + in % gsz) * BM;
+        n0 = (in / gsz) << 8;
+    };
+    // A half h of a stage: rows {group * RG + off_h + [0, len_h)} of both groups = 2 * len_h / 8 pieces of 8 rows; piece slots
+    // s = wave * 2 + j (16 per half); slots past the piece count are dummies
+    auto a_piece_row = [&](int h, int s) __attribute__((always_inline)) -> int {      // first tile row of piece s, or -1
+        const int len8 = (h == 0 ? MF0 : MF1) * 2;                                      // pieces per group
+        if (s >= 2 * len8) return -1;
+        const int grp = s / len8, r8 = s - grp * len8;
+        return grp * RG + (h == 0 ? 0 : MF0 * 16) + r8 * 8;
+    };
+    auto set_offsets = [&](uint32_t (&o)[4][2], int m0, int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int s_ = wave * 2 + j;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r0 = a_piece_row(h, s_);
+                const int ra = r0 + lrow, m = m0 + ra;
+                o[h][j] = (r0 >= 0 && m < g.M) ? (uint32_t)(((long long)m * g.lda0 + ((lch ^ (ra & 7)) << 3)) * 2) : 0x80000000u;
+                const int rh = s_ * 8 + lrow;
+                const int rw = (rh >> 5) * 64 + h * 32 + (rh & 31);
+                o[2 + h][j] = (uint32_t)(((long long)(n0 + rw) * g.K + ((lch ^ (rw & 7)) << 3)) * 2);
+            }
+        }
+    };
+    auto lds_dst = [&](int kind, int j) __attribute__((always_inline)) -> int {   // wave-uniform destination of a piece inside a stage
+        const int s_ = wave * 2 + j;
+        if (kind < 2) {
+            const int r0 = a_piece_row(kind, s_);
+            return (r0 >= 0 ? r0 : BM) * 128;                   // dummy pieces land in the unused rows BM.. of the A region
+        }
+        const int rb = s_ * 8;
+        return A_BYTES + ((rb >> 5) * 64 + (kind - 2) * 32 + (rb & 31)) * 128;
+    };
+
+    const int nk = g.K / BK;
+    uint32_t ocur[4][2], onxt[4][2];
+    int seq = bpos, m0, n0, m0n = 0, n0n = 0;
+    coords(seq, m0, n0);
+    set_offsets(ocur, m0, n0);
+    bool has_next = seq + G < ntiles;
+    if (has_next) { coords(seq + G, m0n, n0n); set_offsets(onxt, m0n, n0n); }
+    int gk = 0;                                                // K tiles consumed so far by this workgroup (stage = gk & 1)
+
+    // half-tile `kind` of K tile t of the CURRENT tile into stage `st` / of K tile tt of the NEXT tile (separate functions:
+    // a run-time choice between the two offset sets makes hipcc index them through scratch memory, and scratch loads count
+    // in vmcnt like the DMA does)
+    auto issue_cur = [&](int kind, int t, int st) __attribute__((always_inline)) {
+        unsigned char* base = smem + (st & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kind < 2 ? rsA : rsW, (lds_void_t)(base + lds_dst(kind, j)), 16,
+                                                     (int)ocur[kind][j], t * 128, 0, 0);
+    };
+    auto issue_nxt = [&](int kind, int tt, int st) __attribute__((always_inline)) {
+        if (!has_next) return;
+        unsigned char* base = smem + (st & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kind < 2 ? rsA : rsW, (lds_void_t)(base + lds_dst(kind, j)), 16,
+                                                     (int)onxt[kind][j], tt * 128, 0, 0);
+    };
+
+    f32x4 acc[NF][MF];
+    bf16x8 fa[4][2], fw[4][2];
+    auto read_a = [&](const unsigned char* A, int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < (h == 0 ? MF0 : MF1); ++j) {
+            const int rr = wrow_m + (h == 0 ? 0 : MF0 * 16) + j * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[j][ks] = *(const bf16x8*)(A + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+        }
+    };
+    auto read_w = [&](const unsigned char* W, int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = wrow_n + h * 32 + i * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fw[h * 2 + i][ks] = *(const bf16x8*)(W + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+        }
+    };
+    auto mma = [&](int mh, int nh) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < (mh == 0 ? MF0 : MF1); ++j)
+                    acc[nh * 2 + i][(mh == 0 ? 0 : MF0) + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nh * 2 + i][ks], fa[j][ks], acc[nh * 2 + i][(mh == 0 ? 0 : MF0) + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto sync_reads = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync_mma = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    __syncthreads();                                           // bias image complete (no DMA in flight yet: a plain barrier)
+    // ---- prologue of the first tile: K tile 0 complete, first three half-tiles of K tile 1 in flight (nk >= 2) ----------
+    issue_cur(0, 0, 0); issue_cur(2, 0, 0); issue_cur(3, 0, 0); issue_cur(1, 0, 0);
+    issue_cur(0, 1, 1); issue_cur(2, 1, 1); issue_cur(3, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    bar();
+    if (wm == 1) bar();                                        // group 1 runs one barrier behind group 0
+
+    // one K tile = 4 phases.  TAIL 0: K tiles t+1, t+2 belong to this tile; 1: t = nk-2 (t+2 is K tile 0 of the next tile);
+    // 2: t = nk-1 (t+1, t+2 are K tiles 0, 1 of the next tile).  Stage of a K tile = parity of the running counter gk.
+    auto ktile = [&](int t, auto tail_c) __attribute__((always_inline)) {
+        constexpr int TAIL = decltype(tail_c)::value;
+        const unsigned char* A = smem + (gk & 1) * STAGE;
+        const unsigned char* W = A + A_BYTES;
+        read_a(A, 0); read_w(W, 0);
+        if constexpr (TAIL == 2) issue_nxt(1, 0, gk + 1); else issue_cur(1, t + 1, gk + 1);
+        sync_reads();
+        mma(0, 0);
+        sync_mma();
+        read_w(W, 1);
+        if constexpr (TAIL == 0) issue_cur(0, t + 2, gk); else issue_nxt(0, TAIL - 1, gk);
+        sync_reads();
+        mma(0, 1);
+        sync_mma();
+        read_a(A, 1);
+        if constexpr (TAIL == 0) issue_cur(2, t + 2, gk); else issue_nxt(2, TAIL - 1, gk);
+        sync_reads();
+        mma(1, 1);
+        sync_mma();
+        if constexpr (TAIL == 0) issue_cur(3, t + 2, gk); else issue_nxt(3, TAIL - 1, gk);
+        if (TAIL == 0 || has_next) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // three half-tiles stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sync_reads();
+        mma(1, 0);
+        sync_mma();
+        ++gk;
+    };
+
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>{});
+        ktile(nk - 2, std::integral_constant<int, 1>{});
+        ktile(nk - 1, std::integral_constant<int, 2>{});
+        // ---- epilogue: 16 rows at a time through this wave's slab; no workgroup barrier (the groups stay one barrier apart) ----
+        {
+            unsigned char* slab = smem + SLAB0 + wave * SLAB;
+            const float* bl = (const float*)(smem + BIAS0) + n0 + wrow_n + fq * 4;
+            if constexpr (!F32OUT) {
+                const bool gelu = g.flags & YV_EPI_GELU;
+                uint16_t* outp = (uint16_t*)g.out;
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 bvi = *(const float4*)(bl + i * 16);
+                        float v0 = acc[i][j][0] + bvi.x, v1 = acc[i][j][1] + bvi.y;
+                        float v2 = acc[i][j][2] + bvi.z, v3 = acc[i][j][3] + bvi.w;
+                        if (gelu) { v0 = gelu_fast_f(v0); v1 = gelu_fast_f(v1); v2 = gelu_fast_f(v2); v3 = gelu_fast_f(v3); }
+                        const int c16 = i * 2 + (fq >> 1);
+                        *(uint2*)(slab + fr * 128 + ((c16 ^ (fr & 7)) << 4) + (fq & 1) * 8) =
+                            make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab is wave-private: LDS executes a wave's ops in order
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                        const int m = m0 + wrow_m + j * 16 + row;
+                        const uint4 pk = *(const uint4*)(slab + row * 128 + ((ch ^ (row & 7)) << 4));
+                        if (m < M) *(uint4*)(outp + (long long)m * g.ldo + n0 + wrow_n + ch * 8) = pk;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the next chunk overwrites the slab
+                }
+            } else {
+                // f32 output / residual stream (x += A . W^T + b): 16 rows x 32 columns per pass (128-byte row segments)
+                float* outp = (float*)g.out;
+                const bool rmw = g.flags & YV_EPI_RES_F32;
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+#pragma unroll
+                    for (int ip = 0; ip < 2; ++ip) {
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            const int i = ip * 2 + ii;
+                            const float4 bvi = *(const float4*)(bl + i * 16);
+                            *(float4*)(slab + fr * 128 + (((ii * 4 + fq) ^ (fr & 7)) << 4)) =
+                                make_float4(acc[i][j][0] + bvi.x, acc[i][j][1] + bvi.y, acc[i][j][2] + bvi.z, acc[i][j][3] + bvi.w);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                            const int m = m0 + wrow_m + j * 16 + row;
+                            float4 v = *(const float4*)(slab + row * 128 + ((ch ^ (row & 7)) << 4));
+                            if (m < M) {
+                                float* o = outp + (long long)m * g.ldo + n0 + wrow_n + ip * 32 + ch * 4;
+                                if (rmw) { const float4 x = *(const float4*)o; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+                                *(float4*)o = v;
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        seq += G;
+        m0 = m0n; n0 = n0n;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ocur[k][0] = onxt[k][0]; ocur[k][1] = onxt[k][1]; }
+        has_next = seq + G < ntiles;
+        if (has_next) { coords(seq + G, m0n, n0n); set_offsets(onxt, m0n, n0n); }
+    }
+    if (wm == 0) bar();                                        // group 0 waits for group 1's last barrier
+}
+
+template <int MF0, int MF1, bool F32OUT>
+int launch_p8_inst2(GemmArgs& g, hipStream_t st, int n_cu) {
+    constexpr int BM = 32 * (MF0 + MF1);
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = g.N / 256;
+    const size_t lds = 2 * 65536 + 8 * 2048 + 16384;
+    auto kern = gemm_p8_kernel<MF0, MF1, F32OUT>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return YV_ERR_LAUNCH;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int grid = tiles < n_cu ? tiles : n_cu;
+    if (t_time_start || t_time_stop) {
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), (uint32_t)lds, st, t_time_start, t_time_stop, 0, g);
+        t_time_start = t_time_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g);
+    }
+    return yv_launch_status();
+}
+
+template <int MF0, int MF1>
+int launch_p8_inst(GemmArgs& g, hipStream_t st, int n_cu) {
+    if (g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32)) return launch_p8_inst2<MF0, MF1, true>(g, st, n_cu);
+    return launch_p8_inst2<MF0, MF1, false>(g, st, n_cu);
+}
+
+int g_opt_p8_rows = 0;             // 0 = pick the tile height per launch; 128 / 160 / 192 / 224 / 256 force it ("linear_p8_rows")
+
+int launch_p8(GemmArgs& g, hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return YV_ERR_LAUNCH;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // tile height: minimise rounds x (rows + a fixed per-tile cost worth ~24 rows: epilogue, pipeline turn-around)
+    int best = 256;
+    if (g_opt_p8_rows) best = g_opt_p8_rows;
+    else {
+        long long best_cost = -1;
+        const int cand[5] = {256, 224, 192, 160, 128};
+        for (int c = 0; c < 5; ++c) {
+            const long long tiles = (long long)((g.M + cand[c] - 1) / cand[c]) * (g.N / 256);
+            const long long rounds = (tiles + n_cu - 1) / n_cu;
+            const long long cost = rounds * (cand[c] + 24);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand[c]; }
+        }
+    }
+    switch (best) {
+        case 224: return launch_p8_inst<4, 3>(g, st, n_cu);
+        case 192: return launch_p8_inst<3, 3>(g, st, n_cu);
+        case 160: return launch_p8_inst<3, 2>(g, st, n_cu);
+        case 128: return launch_p8_inst<2, 2>(g, st, n_cu);
+        default: return launch_p8_inst<4, 4>(g, st, n_cu);
+    }
+}
+
 int launch_8phase(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + 255) / 256;
     g.tiles_n = (g.N + 255) / 256;
@@ -1362,6 +1720,8 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!strcmp(key, "wgrad_split_cap")) { g_opt_wgrad_cap = value; return YV_OK; }
     if (!strcmp(key, "linear_group_m")) { g_opt_group_m = value; return YV_OK; }
     if (!strcmp(key, "staged_epilogue")) { g_opt_staged = value; return YV_OK; }
+    if (!strcmp(key, "linear_p8")) { g_opt_p8 = value; return YV_OK; }
+    if (!strcmp(key, "linear_p8_rows")) { g_opt_p8_rows = value; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_splitk")) { g_opt_linear_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_wide_min_n")) { g_opt_wide_min = value; return YV_OK; }
@@ -1410,11 +1770,20 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
         // Isolated, the 8-phase 256x256 kernel is 3-13 % faster on N >= 1536, but inside the pipeline (operands
         // cold in L2, GELU / residual epilogues) the interleaved end-to-end A/B measures it 1-2 % slower.
         if (variant == 1 && N >= g_opt_wide_min && N <= g_opt_wide_max && M >= 2048) variant = 8;   // 8-phase 256x256
+        // persistent 8-phase kernel: wide bf16-output linears (the qkv / fc1 shapes), see gemm_p8_kernel for its restrictions
+        const bool p8_ok = !(N & 255) && N <= 4096 && K >= 128 &&
+                           !(flags & ~(YV_EPI_BIAS | YV_EPI_GELU | YV_EPI_RES_F32 | YV_EPI_OUT_F32)) &&
+                           !((flags & YV_EPI_GELU) && (flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32))) && g.staged && !res_f32 && !aux &&
+                           ((long long)(M - 1) * lda + K) * 2 < 0x7fffffffLL && (long long)N * K * 2 < 0x7fffffffLL &&
+                           !(ldo & 7) && !(lda & 7);
+        if (variant == 1 && g_opt_p8 && p8_ok && M >= 2048 && (N >= 1536 || g_opt_p8 >= 2)) variant = 9;
+        if (variant == 9 && !p8_ok) variant = 1;
         switch (variant) {
             case 2: return launch_dma<256, 128, 4, 2>(g, stream);
             case 3: return launch_dma<256, 256, 2, 4>(g, stream);
             case 4: return launch_dma<128, 256, 2, 4>(g, stream);
             case 8: return launch_8phase(g, stream);
+            case 9: return launch_p8(g, stream);
             case 201: return launch_dma<256, 256, 2, 4, 1>(g, stream);
             case 202: return launch_dma<256, 256, 2, 4, 2>(g, stream);
             case 203: return launch_dma<256, 256, 2, 4, 3>(g, stream);

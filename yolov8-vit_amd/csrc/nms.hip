@@ -425,37 +425,136 @@ __global__ __launch_bounds__(EN2_FT) void en2_filter_kernel(const float* __restr
     }
 }
 
-// images with more than K candidates: exact selection of the K best (score desc, flat asc), rewritten into the list
+// images with more than K candidates: exact selection of the K best (score desc, flat asc), rewritten into the list.
+// One workgroup per image keeps the image's candidate keys in registers (A*nc <= 48K; larger problems take the bit-serial
+// fallback below) and runs a radix select with 8-bit digits starting at the HIGHEST BIT IN WHICH THE KEYS DIFFER (scores of
+// one detector share sign and most of the exponent: starting at bit 31 would put every key into one or two bins and
+// serialise the LDS atomics).  Histograms are private per wave; ties on the cut key are taken in flat-index order.
+constexpr int ES_CACHE = 44;
 __global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __restrict__ scores, int A, int nc,
                                                                 float score_thr, int K, En2Ws ws) {
+    __shared__ uint32_t hist[16][256];
+    __shared__ uint32_t tot[256];
     __shared__ uint32_t wave_cnt[16];
-    __shared__ uint32_t n_sel_sh, n_eq_sh;
+    __shared__ uint32_t sel[4];                                 // [0] bin, [1] candidates before the bin, [2] AND, [3] OR
     __shared__ uint32_t cc[EN2_CC_LDS];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ws.count[b] <= (uint32_t)K) return;
     const int total = A * nc;
     const float* S = scores + (size_t)b * total;
     const int chunks = (total + EN_THREADS - 1) / EN_THREADS;
-    constexpr int EN_CACHE = 48;
-    const bool cached = chunks <= EN_CACHE;
-    uint32_t kreg[EN_CACHE];
+    uint64_t* list = ws.cand + (size_t)b * K;
+    const bool cc_lds = nc <= EN2_CC_LDS;
+    uint32_t key_star, need_eq;
+    if (chunks <= ES_CACHE) {
+        uint32_t kreg[ES_CACHE];
+        uint32_t ka = 0xFFFFFFFFu, ko = 0u;
 #pragma unroll
-    for (int c = 0; c < EN_CACHE; ++c) {
-        kreg[c] = 0xFFFFFFFFu;
-        const int i = c * EN_THREADS + tid;
-        if (c < chunks && i < total) { const float v = S[i]; if (v > score_thr) kreg[c] = desc_key(v); }
-    }
-    uint32_t prefix = 0, need = (uint32_t)K;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
-        uint32_t c0 = 0;
-        if (cached) {
+        for (int c = 0; c < ES_CACHE; ++c) {
+            kreg[c] = 0xFFFFFFFFu;                                // not a candidate (no real key is ~0: that would be a NaN score)
+            const int i = c * EN_THREADS + tid;
+            if (c < chunks && i < total) { const float v = S[i]; if (v > score_thr) { kreg[c] = desc_key(v); ka &= kreg[c]; ko |= kreg[c]; } }
+        }
 #pragma unroll
-            for (int c = 0; c < EN_CACHE; ++c) {
-                const uint32_t k = kreg[c];
-                c0 += (k != 0xFFFFFFFFu && ((k & hi_mask) == prefix) && !((k >> bit) & 1u)) ? 1u : 0u;
+        for (int o = 32; o > 0; o >>= 1) { ka &= __shfl_xor(ka, o, 64); ko |= __shfl_xor(ko, o, 64); }
+        if (lane == 0) { hist[0][wave] = ka; hist[1][wave] = ko; }
+        __syncthreads();
+        ka = 0xFFFFFFFFu; ko = 0u;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { ka &= hist[0][w]; ko |= hist[1][w]; }
+        __syncthreads();
+        const uint32_t diff = ka ^ ko;
+        uint32_t prefix = ka, need = (uint32_t)K;
+        if (diff) {
+            int pos = 31 - __builtin_clz(diff);
+            prefix = ka & ~((pos == 31) ? 0xFFFFFFFFu : ((2u << pos) - 1u));       // the bits above `pos` are common
+            while (pos >= 0) {
+                const int lo = pos >= 7 ? pos - 7 : 0;
+                const uint32_t nbins = 1u << (pos - lo + 1);
+                const uint32_t hi_mask = pos == 31 ? 0u : ~((2u << pos) - 1u);
+                for (int i = tid; i < 16 * 256; i += EN_THREADS) (&hist[0][0])[i] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < ES_CACHE; ++c) {
+                    const uint32_t k = kreg[c];
+                    if (k != 0xFFFFFFFFu && (k & hi_mask) == prefix) atomicAdd(&hist[wave][(k >> lo) & (nbins - 1u)], 1u);
+                }
+                __syncthreads();
+                if (tid < 256) {
+                    uint32_t t = 0;
+#pragma unroll
+                    for (int w = 0; w < 16; ++w) t += hist[w][tid];
+                    tot[tid] = t;
+                }
+                __syncthreads();
+                if (wave == 0) {                                  // 64 lanes x 4 consecutive bins: find the bin holding the need-th key
+                    const uint32_t t0 = tot[lane * 4], t1 = tot[lane * 4 + 1], t2 = tot[lane * 4 + 2], t3 = tot[lane * 4 + 3];
+                    const uint32_t mine = t0 + t1 + t2 + t3;
+                    uint32_t incl = mine;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+                    const uint32_t before = incl - mine;
+                    if (before < need && need <= incl) {          // exactly one lane
+                        uint32_t bsel = lane * 4, bb = before;
+                        if (need > bb + t0) { bb += t0; ++bsel; if (need > bb + t1) { bb += t1; ++bsel; if (need > bb + t2) { bb += t2; ++bsel; } } }
+                        sel[0] = bsel; sel[1] = bb;
+                    }
+                }
+                __syncthreads();
+                prefix |= sel[0] << lo;
+                need -= sel[1];
+                pos = lo - 1;
             }
-        } else {
+        }
+        key_star = prefix; need_eq = need;
+        // ---- compaction.  Keys below the cut: any order (the consumer sorts).  Keys EQUAL to the cut: when all of them are
+        //      wanted (always, unless scores tie exactly on the cut) they are appended the same way; otherwise the first need_eq
+        //      in flat-index order are chosen by the ordered pass at the end of this kernel (shared with the fallback)
+        uint32_t n_le = 0, n_eq = 0;
+#pragma unroll
+        for (int c = 0; c < ES_CACHE; ++c) {
+            const uint32_t k = kreg[c];
+            n_le += (k <= key_star && k != 0xFFFFFFFFu) ? 1u : 0u;
+            n_eq += (k == key_star && k != 0xFFFFFFFFu) ? 1u : 0u;
+        }
+        uint32_t incl = n_le, eqs = n_eq;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) eqs += __shfl_xor(eqs, o, 64);
+        if (lane == 63) wave_cnt[wave] = incl;
+        if (lane == 0) tot[wave] = eqs;
+        __syncthreads();
+        uint32_t before = 0, eq_total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { if (w < wave) before += wave_cnt[w]; eq_total += tot[w]; }
+        __syncthreads();
+        if (eq_total == need_eq) {                                // uniform: every key up to and including the cut is selected
+            if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) cc[c] = 0;
+            for (int c = tid; c < nc; c += EN_THREADS) ws.ccount[(size_t)b * nc + c] = 0;     // recounted for the selected set
+            __syncthreads();
+            uint32_t pos = before + (incl - n_le);
+#pragma unroll
+            for (int c = 0; c < ES_CACHE; ++c) {
+                const uint32_t k = kreg[c];
+                if (k <= key_star && k != 0xFFFFFFFFu) {
+                    const uint32_t flat = (uint32_t)(c * EN_THREADS + tid);
+                    if (pos < (uint32_t)K) list[pos] = ((uint64_t)k << 32) | flat;
+                    ++pos;
+                    const uint32_t cl = flat % (uint32_t)nc;
+                    if (cc_lds) atomicAdd(&cc[cl], 1u); else atomicAdd(&ws.ccount[(size_t)b * nc + cl], 1u);
+                }
+            }
+            __syncthreads();
+            if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) { const uint32_t n = cc[c]; if (n) ws.ccount[(size_t)b * nc + c] = n; }
+            return;
+        }
+    } else {
+        // ---- more than 48K scores per image: bit-serial select over the scores in L2 (the round-1 algorithm) ------------
+        uint32_t prefix = 0, need = (uint32_t)K;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+            uint32_t c0 = 0;
             for (int c = 0; c < chunks; ++c) {
                 const int i = c * EN_THREADS + tid;
                 if (i < total) {
@@ -463,26 +562,24 @@ __global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __r
                     if (v > score_thr) { const uint32_t k = desc_key(v); c0 += (((k & hi_mask) == prefix) && !((k >> bit) & 1u)) ? 1u : 0u; }
                 }
             }
+            uint32_t w = c0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+            __syncthreads();
+            if (lane == 0) wave_cnt[wave] = w;
+            __syncthreads();
+            uint32_t t0 = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t0 += wave_cnt[q];
+            if (need > t0) { need -= t0; prefix |= (1u << bit); }
         }
-        uint32_t w = c0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
-        __syncthreads();
-        if ((tid & 63) == 0) wave_cnt[tid >> 6] = w;
-        __syncthreads();
-        uint32_t t0 = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t0 += wave_cnt[q];
-        if (need > t0) { need -= t0; prefix |= (1u << bit); }
+        key_star = prefix; need_eq = need;
     }
-    const uint32_t key_star = prefix, need_eq = need;
-    const bool cc_lds = nc <= EN2_CC_LDS;
+    // ---- ordered compaction (scores re-read from L2, chunk by chunk): ties on the cut key in flat-index order ---------------
     if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) cc[c] = 0;
-    for (int c = tid; c < nc; c += EN_THREADS) ws.ccount[(size_t)b * nc + c] = 0;     // recounted for the selected set
-    if (tid == 0) { n_sel_sh = 0; n_eq_sh = 0; }
+    for (int c = tid; c < nc; c += EN_THREADS) ws.ccount[(size_t)b * nc + c] = 0;
+    if (tid == 0) { sel[0] = 0; sel[1] = 0; }                     // [0] selected so far, [1] cut-key ties seen so far
     __syncthreads();
-    __threadfence_block();
-    uint64_t* list = ws.cand + (size_t)b * K;
     for (int c = 0; c < chunks; ++c) {
         const int i = c * EN_THREADS + tid;
         bool pass = false, eq = false;
@@ -491,15 +588,15 @@ __global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __r
             const float v = S[i];
             if (v > score_thr) { k = desc_key(v); pass = k < key_star; eq = k == key_star; }
         }
-        uint32_t tot;
-        const uint32_t r = block_rank(eq, wave_cnt, &tot);          // ties on the cut score: lowest flat index first
-        const uint32_t base = n_eq_sh;
+        uint32_t tt;
+        const uint32_t r = block_rank(eq, wave_cnt, &tt);
+        const uint32_t base = sel[1];
         const bool take = pass || (eq && base + r < need_eq);
         __syncthreads();
-        if (tid == 0) n_eq_sh = base + tot;
+        if (tid == 0) sel[1] = base + tt;
         if (take) {
-            const uint32_t pos = atomicAdd(&n_sel_sh, 1u);
-            if (pos < (uint32_t)K) list[pos] = ((uint64_t)k << 32) | (uint32_t)i;
+            const uint32_t at = atomicAdd(&sel[0], 1u);
+            if (at < (uint32_t)K) list[at] = ((uint64_t)k << 32) | (uint32_t)i;
             const uint32_t cl = (uint32_t)i % (uint32_t)nc;
             if (cc_lds) atomicAdd(&cc[cl], 1u); else atomicAdd(&ws.ccount[(size_t)b * nc + cl], 1u);
         }
@@ -508,7 +605,7 @@ __global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __r
     if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) { const uint32_t n = cc[c]; if (n) ws.ccount[(size_t)b * nc + c] = n; }
 }
 
-// per-class greedy NMS over one image's candidate list.  TIER 0: classes with <= 512 candidates (256 threads, 12 KB of LDS,
+// per-class greedy NMS over one image's candidate list.  TIER 0: classes with <= 1024 candidates (256 threads, 26 KB of LDS,
 // several workgroups per CU); TIER 1: up to 4096 (1024 threads).  Both are launched over the same (nc, B) grid and a
 // workgroup leaves at once when the class belongs to the other tier (the count is only known on the device).
 template <int CAP, int THREADS>
@@ -598,17 +695,17 @@ __device__ __forceinline__ void en2_one_class(unsigned char* smem, const float* 
     __syncthreads();
 }
 
-// TIER 0: one workgroup per (class, image), classes with 1..512 candidates
+// TIER 0: one workgroup per (class, image), classes with 1..1024 candidates
 __global__ __launch_bounds__(256) void en2_class_small_kernel(const float* __restrict__ boxes, int A, int nc, float iou_thr,
                                                               int max_out, int K, En2Ws ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int c = blockIdx.x, b = blockIdx.y;
     const uint32_t n_c = ws.ccount[(size_t)b * nc + c];
-    if (n_c == 0 || n_c > 512u) return;                        // nkept was zeroed by the memset node of this call
-    en2_one_class<512, 256>(smem, boxes, A, nc, c, b, iou_thr, max_out, K, ws);
+    if (n_c == 0 || n_c > 1024u) return;                       // nkept was zeroed by the memset node of this call
+    en2_one_class<1024, 256>(smem, boxes, A, nc, c, b, iou_thr, max_out, K, ws);
 }
 
-// TIER 1: one workgroup per image walks the image's heavy classes (more than 512 candidates: at most K / 512 of them)
+// TIER 1: one workgroup per image walks the image's heavy classes (more than 1024 candidates: at most K / 1024 of them)
 __global__ __launch_bounds__(1024) void en2_class_large_kernel(const float* __restrict__ boxes, int A, int nc, float iou_thr,
                                                                int max_out, int K, En2Ws ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -618,7 +715,7 @@ __global__ __launch_bounds__(1024) void en2_class_large_kernel(const float* __re
     if (tid == 0) n_heavy = 0;
     __syncthreads();
     for (int c = tid; c < nc; c += 1024)
-        if (ws.ccount[(size_t)b * nc + c] > 512u) { const uint32_t p = atomicAdd(&n_heavy, 1u); if (p < 16u) heavy[p] = (uint32_t)c; }
+        if (ws.ccount[(size_t)b * nc + c] > 1024u) { const uint32_t p = atomicAdd(&n_heavy, 1u); if (p < 16u) heavy[p] = (uint32_t)c; }
     __syncthreads();
     const int nh = (int)(n_heavy < 16u ? n_heavy : 16u);
     for (int h = 0; h < nh; ++h) en2_one_class<EN_MAXK, 1024>(smem, boxes, A, nc, (int)heavy[h], b, iou_thr, max_out, K, ws);
@@ -907,7 +1004,7 @@ extern "C" int yv_efficient_nms_ws(const float* boxes, const float* scores, int 
     hipLaunchKernelGGL(en2_filter_kernel, dim3(chunks, B), dim3(EN2_FT), 0, st, scores, total, nc, score_threshold, pre_topk, w);
     hipLaunchKernelGGL(en2_select_kernel, dim3(B), dim3(EN_THREADS), 0, st, scores, A, nc, score_threshold, pre_topk, w);
     auto lds_of = [&](int cap, int nw) { return (size_t)cap * (8 + 16) + (size_t)max_out * 16 + 64 * 8 + (size_t)nw * 8 + 16; };
-    const size_t lds0 = lds_of(512, 4), lds1 = lds_of(EN_MAXK, 16);
+    const size_t lds0 = lds_of(1024, 4), lds1 = lds_of(EN_MAXK, 16);
     if (hipFuncSetAttribute((const void*)en2_class_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) !=
         hipSuccess)
         return YV_ERR_LAUNCH;
