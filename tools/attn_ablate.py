@@ -8,7 +8,7 @@ g = torch.Generator().manual_seed(0)
 qkv = torch.randn(R * N, 3 * H * 64, generator=g).to(torch.bfloat16).to(dev)
 out = torch.zeros(R * N, H * 64, dtype=torch.bfloat16, device=dev)
 big = torch.zeros(64 * 1024 * 1024, device=dev)
-for abl in (0, 1, 2, 3, 0):
+for abl in (0, 4, 1, 2, 3, 0, 4):   # 0 = shipped (online softmax per 32-key group), 4 = round-1 form, 1-3 = ablations of the round-1 form
     yvhip.lib.yv_attention_debug(abl)
     ts = []
     for rd in range(5):

@@ -28,11 +28,11 @@ int g_attn_abl = 0;               // diagnostic builds (yv_attention_debug)
 // optional MXFP8 image of the output (operand of the proj GEMM of yv_linear_mxfp8): e4m3 bytes + E8M0 per 32 columns
 struct AttnMx { uint8_t* q; long long ldq; uint8_t* s; long long rows; };
 
-// SINGLE (N <= NP, the ViT-x/16 case: 197 tokens in one 224-row tile): the score block is computed TWICE - pass 1 keeps only
-// the row maximum, pass 2 recomputes each 32-key group, exponentiates it and feeds it to the PV product at once - instead
-// of holding all NT groups (16 f32 registers each) across the softmax.  28 extra MFMAs per wave buy a register budget
-// under 128, i.e. TWO workgroups per CU instead of one (round 1: 194 VGPRs, one 7-wave workgroup per CU, every global ->
-// LDS staging fully exposed).  Same operation order as before: the outputs are bit-identical to the one-pass form.
+// SINGLE (N <= NP, the ViT-x/16 case: 197 tokens in one 224-row tile): the 32-key score groups are consumed one at a time with
+// an online softmax (running max / sum per query, O rescaled only when some row's maximum really grew - typically 2-3 of the
+// 7 groups) instead of holding all NT groups (16 f32 registers each) across the softmax: ~100 VGPRs instead of 194, i.e. TWO
+// workgroups per CU, so that one workgroup's global -> LDS staging (HBM-bound: 155 MB per launch at 128 crops) runs under the
+// other's MFMA / exp work.  Round-1 form: one 7-wave workgroup per CU, staging (29 us) and compute (40 us) back to back.
 template <int NT, int ABL = 0, bool SINGLE = false>
 __global__ __launch_bounds__(NT * 64, SINGLE ? 4 : 1) void attention_kernel(const uint16_t* __restrict__ qkv, int N, int H, int QB,
                                                             float scale_log2e, uint16_t* __restrict__ out,
@@ -94,7 +94,9 @@ __global__ __launch_bounds__(NT * 64, SINGLE ? 4 : 1) void attention_kernel(cons
         if (ABL == 2) continue;
 
         if constexpr (SINGLE) {
-            auto scores = [&](int kt) __attribute__((always_inline)) -> f32x16 {
+            float l_lane = 0.f;                               // this lane's share of the row sum (lane ^ 32 holds the rest)
+#pragma unroll 1
+            for (int kt = 0; kt < NT; ++kt) {                // rolled: unrolled, the scheduler hoists every group's MFMAs again
                 f32x16 sv;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sv[e] = 0.f;
@@ -112,28 +114,25 @@ __global__ __launch_bounds__(NT * 64, SINGLE ? 4 : 1) void attention_kernel(cons
                         sv[e] = key < N ? sv[e] : -INFINITY;
                     }
                 }
-                return sv;
-            };
-            float mx = -INFINITY;
-#pragma unroll 1
-            for (int kt = 0; kt < NT; ++kt) {            // rolled loops: unrolled, the scheduler hoists all NT score blocks again
-                const f32x16 sv = scores(kt);
+                float mx = sv[0];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sv[e]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mb = mx * scale_log2e;
-            float l = 0.f;
-            // the second pass must really recompute: without this the compiler keeps pass 1's score registers alive (CSE)
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sv[e]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run, mx);        // group 0 holds valid keys for every row -> finite from then on
+                if (__any(m_new > m_run)) {                  // wave-uniform: some query's maximum grew
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);   // 1 for unchanged rows, 0 at the start
+                    l_lane *= alpha;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(fq[ks]));
-#pragma unroll 1
-            for (int kt = 0; kt < NT; ++kt) {
-                f32x16 sv = scores(kt);
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) o[mt][e] *= alpha;
+                    m_run = m_new;
+                }
+                const float mb = m_run * scale_log2e;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     sv[e] = __builtin_amdgcn_exp2f(fmaf(sv[e], scale_log2e, -mb));
-                    l += sv[e];
+                    l_lane += sv[e];
                 }
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
@@ -151,9 +150,7 @@ __global__ __launch_bounds__(NT * 64, SINGLE ? 4 : 1) void attention_kernel(cons
                     }
                 }
             }
-            l += __shfl_xor(l, 32, 64);
-            l_run = l;
-            m_run = mx;
+            l_run = l_lane + __shfl_xor(l_lane, 32, 64);
             continue;
         }
 
@@ -285,7 +282,7 @@ int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t*
                 hipStream_t st, AttnMx mx) {
     constexpr int NP = NT * 32;
     const size_t lds = (size_t)NP * 128 + 64 * (size_t)(NP * 2 + 8);
-    const bool single = N <= NP && g_attn_abl != 4;           // ablation 4: the round-1 one-pass form of the single-tile case
+    const bool single = N <= NP && g_attn_abl != 4;           // ablation 4: the round-1 form of the single-tile case (all groups held)
     auto kern = g_attn_abl == 1 ? attention_kernel<NT, 1> : g_attn_abl == 2 ? attention_kernel<NT, 2> : g_attn_abl == 3 ? attention_kernel<NT, 3> :
                 single ? attention_kernel<NT, 0, true> : attention_kernel<NT, 0, false>;
     if (lds > 65536 &&

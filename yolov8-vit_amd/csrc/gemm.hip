@@ -1336,33 +1336,58 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the next chunk overwrites the slab
                 }
             } else {
-                // f32 output / residual stream (x += A . W^T + b): 16 rows x 32 columns per pass (128-byte row segments)
+                // f32 output / residual stream (x += A . W^T + b): 16 rows x 32 columns per pass (128-byte row segments).
+                // The residual values are fetched for a half / quarter of the wave tile at once, in the row-segment layout of the
+                // stores (8-12 independent 16-byte loads per lane in flight): fetched chunk by chunk, each of the 16 passes of a tile
+                // waited for its own HBM round trip (proj: 67 us for a 39 us memory floor)
                 float* outp = (float*)g.out;
                 const bool rmw = g.flags & YV_EPI_RES_F32;
+                constexpr int NPART = MF <= 5 ? 2 : 4;             // residual registers in flight: 16 * JA (the accumulators hold 16 * MF)
+                constexpr int JA = (MF + NPART - 1) / NPART;
 #pragma unroll
-                for (int j = 0; j < MF; ++j) {
+                for (int half = 0; half < NPART; ++half) {
+                    const int j0 = half * JA, jn = (MF - j0) < JA ? (MF - j0 > 0 ? MF - j0 : 0) : JA;
+                    float4 xr[JA][2][2];
+                    if (rmw) {
 #pragma unroll
-                    for (int ip = 0; ip < 2; ++ip) {
+                        for (int jj = 0; jj < JA; ++jj)
 #pragma unroll
-                        for (int ii = 0; ii < 2; ++ii) {
-                            const int i = ip * 2 + ii;
-                            const float4 bvi = *(const float4*)(bl + i * 16);
-                            *(float4*)(slab + fr * 128 + (((ii * 4 + fq) ^ (fr & 7)) << 4)) =
-                                make_float4(acc[i][j][0] + bvi.x, acc[i][j][1] + bvi.y, acc[i][j][2] + bvi.z, acc[i][j][3] + bvi.w);
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
-                        for (int it = 0; it < 2; ++it) {
-                            const int row = it * 8 + (lane >> 3), ch = lane & 7;
-                            const int m = m0 + wrow_m + j * 16 + row;
-                            float4 v = *(const float4*)(slab + row * 128 + ((ch ^ (row & 7)) << 4));
-                            if (m < M) {
-                                float* o = outp + (long long)m * g.ldo + n0 + wrow_n + ip * 32 + ch * 4;
-                                if (rmw) { const float4 x = *(const float4*)o; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
-                                *(float4*)o = v;
+                                for (int it = 0; it < 2; ++it) {
+                                    const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                                    const int m = m0 + wrow_m + (j0 + jj) * 16 + row;
+                                    xr[jj][ip][it] = (jj < jn && m < M)
+                                        ? *(const float4*)(outp + (long long)m * g.ldo + n0 + wrow_n + ip * 32 + ch * 4)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                                }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < JA; ++jj) {
+                        if (jj >= jn) continue;
+                        const int j = j0 + jj;
+#pragma unroll
+                        for (int ip = 0; ip < 2; ++ip) {
+#pragma unroll
+                            for (int ii = 0; ii < 2; ++ii) {
+                                const int i = ip * 2 + ii;
+                                const float4 bvi = *(const float4*)(bl + i * 16);
+                                *(float4*)(slab + fr * 128 + (((ii * 4 + fq) ^ (fr & 7)) << 4)) =
+                                    make_float4(acc[i][j][0] + bvi.x, acc[i][j][1] + bvi.y, acc[i][j][2] + bvi.z, acc[i][j][3] + bvi.w);
                             }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int it = 0; it < 2; ++it) {
+                                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                                const int m = m0 + wrow_m + j * 16 + row;
+                                float4 v = *(const float4*)(slab + row * 128 + ((ch ^ (row & 7)) << 4));
+                                if (m < M) {
+                                    if (rmw) { const float4 x = xr[jj][ip][it]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+                                    *(float4*)(outp + (long long)m * g.ldo + n0 + wrow_n + ip * 32 + ch * 4) = v;
+                                }
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                 }
             }
@@ -1400,26 +1425,35 @@ int launch_p8_inst2(GemmArgs& g, hipStream_t st, int n_cu) {
 
 template <int MF0, int MF1>
 int launch_p8_inst(GemmArgs& g, hipStream_t st, int n_cu) {
-    if (g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32)) return launch_p8_inst2<MF0, MF1, true>(g, st, n_cu);
+    // the f32 epilogue keeps a residual prefetch next to the accumulators: only the tiles up to 192 rows have the registers for it
+    if constexpr (MF0 + MF1 <= 6) {
+        if (g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32)) return launch_p8_inst2<MF0, MF1, true>(g, st, n_cu);
+    }
     return launch_p8_inst2<MF0, MF1, false>(g, st, n_cu);
 }
 
+int g_opt_p8_cus = 0;              // persistent grid size; 0 = every CU ("linear_p8_cus": leave CUs to concurrent streams)
 int g_opt_p8_rows = 0;             // 0 = pick the tile height per launch; 128 / 160 / 192 / 224 / 256 force it ("linear_p8_rows")
 
 int launch_p8(GemmArgs& g, hipStream_t st) {
-    static int n_cu = 0;
-    if (!n_cu) {
+    static int n_cu_dev = 0;                                    // CU count of the device (same value from every thread)
+    if (!n_cu_dev) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return YV_ERR_LAUNCH;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        n_cu_dev = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    const int n_cu = (g_opt_p8_cus > 0 && g_opt_p8_cus < n_cu_dev) ? g_opt_p8_cus : n_cu_dev;
     // tile height: minimise rounds x (rows + a fixed per-tile cost worth ~24 rows: epilogue, pipeline turn-around)
     int best = 256;
-    if (g_opt_p8_rows) best = g_opt_p8_rows;
-    else {
+    if (g_opt_p8_rows) {
+        best = g_opt_p8_rows;
+        if ((g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32)) && best > 192) best = 192;
+    } else {
         long long best_cost = -1;
         const int cand[5] = {256, 224, 192, 160, 128};
-        for (int c = 0; c < 5; ++c) {
+        const bool f32out = g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32);
+        best = f32out ? 192 : 256;
+        for (int c = f32out ? 2 : 0; c < 5; ++c) {
             const long long tiles = (long long)((g.M + cand[c] - 1) / cand[c]) * (g.N / 256);
             const long long rounds = (tiles + n_cu - 1) / n_cu;
             const long long cost = rounds * (cand[c] + 24);
@@ -1722,6 +1756,7 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!strcmp(key, "staged_epilogue")) { g_opt_staged = value; return YV_OK; }
     if (!strcmp(key, "linear_p8")) { g_opt_p8 = value; return YV_OK; }
     if (!strcmp(key, "linear_p8_rows")) { g_opt_p8_rows = value; return YV_OK; }
+    if (!strcmp(key, "linear_p8_cus")) { g_opt_p8_cus = value; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_splitk")) { g_opt_linear_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_wide_min_n")) { g_opt_wide_min = value; return YV_OK; }

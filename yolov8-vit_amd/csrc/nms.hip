@@ -357,11 +357,13 @@ constexpr int EN2_FPT = 16;                 // filter: scores per thread  -> 409
 constexpr int EN2_CC_LDS = 2048;            // per-class counters staged in LDS up to this many classes
 
 struct En2Ws {                              // device pointers into the caller's workspace (see yv_efficient_nms_ws_bytes)
-    uint64_t* cand;                         // (B, pre_topk)
+    uint64_t* cand;                         // (B, lcap)  lcap = list capacity >= pre_topk (see en2_lcap)
+    int lcap;
     uint64_t* kept;                         // (B, nc, max_out)
     uint32_t* count;                        // (B)      candidates of the image (may exceed pre_topk)
     uint32_t* ccount;                       // (B, nc)  candidates per class (of the selected set)
     uint32_t* nkept;                        // (B, nc)
+    uint32_t* done;                         // (B)      1: en2_head_kernel produced the image's final outputs
 };
 
 __device__ __forceinline__ float key_score(uint32_t key) {          // inverse of desc_key
@@ -408,12 +410,12 @@ __global__ __launch_bounds__(EN2_FT) void en2_filter_kernel(const float* __restr
     __syncthreads();
     if (tot == 0) return;
     uint32_t pos = base_sh + before + (incl - mine);
-    uint64_t* list = ws.cand + (size_t)b * K;
+    uint64_t* list = ws.cand + (size_t)b * ws.lcap;
 #pragma unroll
     for (int j = 0; j < EN2_FPT; ++j) {
         const int i = i0 + j * EN2_FT + tid;
         if (i < total && v[j] > thr) {
-            if (pos < (uint32_t)K) list[pos] = ((uint64_t)desc_key(v[j]) << 32) | (uint32_t)i;
+            if (pos < (uint32_t)ws.lcap) list[pos] = ((uint64_t)desc_key(v[j]) << 32) | (uint32_t)i;
             ++pos;
             const uint32_t c = (uint32_t)i % (uint32_t)nc;
             if (cc_lds) atomicAdd(&cc[c], 1u); else atomicAdd(&ws.ccount[(size_t)b * nc + c], 1u);
@@ -431,82 +433,118 @@ __global__ __launch_bounds__(EN2_FT) void en2_filter_kernel(const float* __restr
 // one detector share sign and most of the exponent: starting at bit 31 would put every key into one or two bins and
 // serialise the LDS atomics).  Histograms are private per wave; ties on the cut key are taken in flat-index order.
 constexpr int ES_CACHE = 44;
+struct SelLds {
+    uint32_t hist[16][256];
+    uint32_t tot[256];
+    uint32_t wave_cnt[16];
+    uint32_t sel[4];
+};
+
+// K-th smallest of the candidate keys held in registers (sentinel ~0 = no candidate) by the 1024 threads of a workgroup: 8-bit
+// radix digits from the highest differing bit down.  Returns (uniformly) the cut key and how many keys EQUAL to it belong to
+// the K smallest.  Requires at least K candidates.
+template <int NR>
+__device__ __forceinline__ void radix_select_regs(const uint32_t (&kreg)[NR], uint32_t K, SelLds& L, uint32_t& key_star,
+                                                  uint32_t& need_eq) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t ka = 0xFFFFFFFFu, ko = 0u;
+#pragma unroll
+    for (int c = 0; c < NR; ++c)
+        if (kreg[c] != 0xFFFFFFFFu) { ka &= kreg[c]; ko |= kreg[c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ka &= __shfl_xor(ka, o, 64); ko |= __shfl_xor(ko, o, 64); }
+    __syncthreads();
+    if (lane == 0) { L.hist[0][wave] = ka; L.hist[1][wave] = ko; }
+    __syncthreads();
+    ka = 0xFFFFFFFFu; ko = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { ka &= L.hist[0][w]; ko |= L.hist[1][w]; }
+    __syncthreads();
+    const uint32_t diff = ka ^ ko;
+    uint32_t prefix = ka, need = K;
+    if (diff) {
+        int pos = 31 - __builtin_clz(diff);
+        prefix = ka & ~((pos == 31) ? 0xFFFFFFFFu : ((2u << pos) - 1u));       // the bits above `pos` are common
+        while (pos >= 0) {
+            const int lo = pos >= 7 ? pos - 7 : 0;
+            const uint32_t nbins = 1u << (pos - lo + 1);
+            const uint32_t hi_mask = pos == 31 ? 0u : ~((2u << pos) - 1u);
+            for (int i = tid; i < 16 * 256; i += EN_THREADS) (&L.hist[0][0])[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                const uint32_t k = kreg[c];
+                if (k != 0xFFFFFFFFu && (k & hi_mask) == prefix) atomicAdd(&L.hist[wave][(k >> lo) & (nbins - 1u)], 1u);
+            }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t t = 0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) t += L.hist[w][tid];
+                L.tot[tid] = t;
+            }
+            __syncthreads();
+            if (wave == 0) {                                  // 64 lanes x 4 consecutive bins: find the bin holding the need-th key
+                const uint32_t t0 = L.tot[lane * 4], t1 = L.tot[lane * 4 + 1], t2 = L.tot[lane * 4 + 2], t3 = L.tot[lane * 4 + 3];
+                const uint32_t mine = t0 + t1 + t2 + t3;
+                uint32_t incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+                const uint32_t before = incl - mine;
+                if (before < need && need <= incl) {          // exactly one lane
+                    uint32_t bsel = lane * 4, bb = before;
+                    if (need > bb + t0) { bb += t0; ++bsel; if (need > bb + t1) { bb += t1; ++bsel; if (need > bb + t2) { bb += t2; ++bsel; } } }
+                    L.sel[0] = bsel; L.sel[1] = bb;
+                }
+            }
+            __syncthreads();
+            prefix |= L.sel[0] << lo;
+            need -= L.sel[1];
+            pos = lo - 1;
+        }
+    }
+    key_star = prefix; need_eq = need;
+}
+
+// block-wide exclusive position of this thread's `mine` items (thread order) and the total; uses L.wave_cnt
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, SelLds& L, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    __syncthreads();
+    if (lane == 63) L.wave_cnt[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint32_t v = L.wave_cnt[w]; if (w < wave) before += v; tot += v; }
+    total = tot;
+    return before + incl - mine;
+}
+
 __global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __restrict__ scores, int A, int nc,
                                                                 float score_thr, int K, En2Ws ws) {
-    __shared__ uint32_t hist[16][256];
-    __shared__ uint32_t tot[256];
-    __shared__ uint32_t wave_cnt[16];
-    __shared__ uint32_t sel[4];                                 // [0] bin, [1] candidates before the bin, [2] AND, [3] OR
+    __shared__ SelLds L;
     __shared__ uint32_t cc[EN2_CC_LDS];
+    uint32_t (&wave_cnt)[16] = L.wave_cnt;
+    uint32_t (&sel)[4] = L.sel;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (ws.count[b] <= (uint32_t)K) return;
+    if (ws.done[b] || ws.count[b] <= (uint32_t)K) return;
     const int total = A * nc;
     const float* S = scores + (size_t)b * total;
     const int chunks = (total + EN_THREADS - 1) / EN_THREADS;
-    uint64_t* list = ws.cand + (size_t)b * K;
+    uint64_t* list = ws.cand + (size_t)b * ws.lcap;
     const bool cc_lds = nc <= EN2_CC_LDS;
     uint32_t key_star, need_eq;
     if (chunks <= ES_CACHE) {
         uint32_t kreg[ES_CACHE];
-        uint32_t ka = 0xFFFFFFFFu, ko = 0u;
 #pragma unroll
         for (int c = 0; c < ES_CACHE; ++c) {
             kreg[c] = 0xFFFFFFFFu;                                // not a candidate (no real key is ~0: that would be a NaN score)
             const int i = c * EN_THREADS + tid;
-            if (c < chunks && i < total) { const float v = S[i]; if (v > score_thr) { kreg[c] = desc_key(v); ka &= kreg[c]; ko |= kreg[c]; } }
+            if (c < chunks && i < total) { const float v = S[i]; if (v > score_thr) kreg[c] = desc_key(v); }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { ka &= __shfl_xor(ka, o, 64); ko |= __shfl_xor(ko, o, 64); }
-        if (lane == 0) { hist[0][wave] = ka; hist[1][wave] = ko; }
-        __syncthreads();
-        ka = 0xFFFFFFFFu; ko = 0u;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { ka &= hist[0][w]; ko |= hist[1][w]; }
-        __syncthreads();
-        const uint32_t diff = ka ^ ko;
-        uint32_t prefix = ka, need = (uint32_t)K;
-        if (diff) {
-            int pos = 31 - __builtin_clz(diff);
-            prefix = ka & ~((pos == 31) ? 0xFFFFFFFFu : ((2u << pos) - 1u));       // the bits above `pos` are common
-            while (pos >= 0) {
-                const int lo = pos >= 7 ? pos - 7 : 0;
-                const uint32_t nbins = 1u << (pos - lo + 1);
-                const uint32_t hi_mask = pos == 31 ? 0u : ~((2u << pos) - 1u);
-                for (int i = tid; i < 16 * 256; i += EN_THREADS) (&hist[0][0])[i] = 0;
-                __syncthreads();
-#pragma unroll
-                for (int c = 0; c < ES_CACHE; ++c) {
-                    const uint32_t k = kreg[c];
-                    if (k != 0xFFFFFFFFu && (k & hi_mask) == prefix) atomicAdd(&hist[wave][(k >> lo) & (nbins - 1u)], 1u);
-                }
-                __syncthreads();
-                if (tid < 256) {
-                    uint32_t t = 0;
-#pragma unroll
-                    for (int w = 0; w < 16; ++w) t += hist[w][tid];
-                    tot[tid] = t;
-                }
-                __syncthreads();
-                if (wave == 0) {                                  // 64 lanes x 4 consecutive bins: find the bin holding the need-th key
-                    const uint32_t t0 = tot[lane * 4], t1 = tot[lane * 4 + 1], t2 = tot[lane * 4 + 2], t3 = tot[lane * 4 + 3];
-                    const uint32_t mine = t0 + t1 + t2 + t3;
-                    uint32_t incl = mine;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-                    const uint32_t before = incl - mine;
-                    if (before < need && need <= incl) {          // exactly one lane
-                        uint32_t bsel = lane * 4, bb = before;
-                        if (need > bb + t0) { bb += t0; ++bsel; if (need > bb + t1) { bb += t1; ++bsel; if (need > bb + t2) { bb += t2; ++bsel; } } }
-                        sel[0] = bsel; sel[1] = bb;
-                    }
-                }
-                __syncthreads();
-                prefix |= sel[0] << lo;
-                need -= sel[1];
-                pos = lo - 1;
-            }
-        }
-        key_star = prefix; need_eq = need;
+        radix_select_regs(kreg, (uint32_t)K, L, key_star, need_eq);
         // ---- compaction.  Keys below the cut: any order (the consumer sorts).  Keys EQUAL to the cut: when all of them are
         //      wanted (always, unless scores tie exactly on the cut) they are appended the same way; otherwise the first need_eq
         //      in flat-index order are chosen by the ordered pass at the end of this kernel (shared with the fallback)
@@ -517,23 +555,15 @@ __global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __r
             n_le += (k <= key_star && k != 0xFFFFFFFFu) ? 1u : 0u;
             n_eq += (k == key_star && k != 0xFFFFFFFFu) ? 1u : 0u;
         }
-        uint32_t incl = n_le, eqs = n_eq;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) eqs += __shfl_xor(eqs, o, 64);
-        if (lane == 63) wave_cnt[wave] = incl;
-        if (lane == 0) tot[wave] = eqs;
-        __syncthreads();
-        uint32_t before = 0, eq_total = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { if (w < wave) before += wave_cnt[w]; eq_total += tot[w]; }
+        uint32_t le_total, eq_total;
+        (void)block_excl_scan(n_eq, L, eq_total);
+        const uint32_t first = block_excl_scan(n_le, L, le_total);
         __syncthreads();
         if (eq_total == need_eq) {                                // uniform: every key up to and including the cut is selected
             if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) cc[c] = 0;
             for (int c = tid; c < nc; c += EN_THREADS) ws.ccount[(size_t)b * nc + c] = 0;     // recounted for the selected set
             __syncthreads();
-            uint32_t pos = before + (incl - n_le);
+            uint32_t pos = first;
 #pragma unroll
             for (int c = 0; c < ES_CACHE; ++c) {
                 const uint32_t k = kreg[c];
@@ -605,6 +635,213 @@ __global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __r
     if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) { const uint32_t n = cc[c]; if (n) ws.ccount[(size_t)b * nc + c] = n; }
 }
 
+// Fast path, one workgroup per image: the sequential scan only ever looks at the candidates ranked before the max_out-th
+// kept box, which for ordinary detections is a short prefix of the ranking.  So: take the EN2_HEAD best candidates (radix
+// select over register-resident keys), order them (rank sort: 512 x 512 comparisons spread over 1024 threads, two barriers -
+// a bitonic network would need 45), walk them in 64-wide tiles exactly like en2_one_class but with the class test inside
+// the suppression predicate, and stop at max_out kept.  If max_out boxes were kept - or every candidate of the image was in
+// the head - the result IS the sequential result and the image is marked done; otherwise (heavy suppression, ties on the
+// head's cut key, more than 45K scores) the general kernels below redo the image from scratch.
+constexpr int EN2_HEAD = 512;
+constexpr int EN2_HR = 16;                  // candidate keys per thread held by en2_head_kernel (16 x 1024 = the list capacity)
+__global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                              int A, int nc, float score_thr, float iou_thr, int max_out, int K,
+                                                              En2Ws ws, int32_t* __restrict__ num_dets,
+                                                              float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                              int32_t* __restrict__ out_labels) {
+    __shared__ SelLds L;
+    __shared__ uint64_t keys[EN2_HEAD];                        // unordered, then sorted
+    __shared__ uint64_t tmpk[EN2_HEAD];
+    __shared__ uint32_t rank[EN2_HEAD];
+    __shared__ float4 sb[EN2_HEAD];
+    __shared__ uint16_t scl[EN2_HEAD];
+    __shared__ uint64_t Mrow[64];
+    __shared__ uint64_t dead[16];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];     // kept boxes (max_out float4), classes, keys
+    float4* kbox = (float4*)dyn;
+    uint64_t* kkey = (uint64_t*)(kbox + max_out);
+    uint16_t* kcl = (uint16_t*)(kkey + max_out);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = A * nc;
+    const float* S = scores + (size_t)b * total;
+    // the image's candidates were compacted by en2_filter_kernel (launched before this kernel): up to 16 of them per thread
+    const uint32_t cnt = ws.count[b];
+    if (cnt > (uint32_t)ws.lcap || cnt > (uint32_t)(EN2_HR * EN_THREADS)) return;      // done stays 0: general path
+    const uint64_t* list = ws.cand + (size_t)b * ws.lcap;
+    uint32_t kreg[EN2_HR], freg[EN2_HR];
+#pragma unroll
+    for (int c = 0; c < EN2_HR; ++c) {
+        const uint32_t i = (uint32_t)(c * EN_THREADS + tid);
+        kreg[c] = 0xFFFFFFFFu; freg[c] = 0;
+        if (i < cnt) { const uint64_t k = list[i]; kreg[c] = (uint32_t)(k >> 32); freg[c] = (uint32_t)k; }
+    }
+    const uint32_t head = (uint32_t)(K < EN2_HEAD ? K : EN2_HEAD);
+    uint32_t key_star = 0xFFFFFFFEu;                            // take every candidate
+    if (cnt > head) {
+        // ANY prefix of the ranking with between head/2 and head members will do, so the cut is put on a radix-digit boundary:
+        // usually ONE histogram pass (8 bits below the highest bit in which the keys differ), a second one only when the
+        // boundary bin straddles the window; a digit boundary never splits equal keys, so ties need no care here
+        uint32_t ka = 0xFFFFFFFFu, ko = 0u;
+#pragma unroll
+        for (int c = 0; c < EN2_HR; ++c)
+            if (kreg[c] != 0xFFFFFFFFu) { ka &= kreg[c]; ko |= kreg[c]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ka &= __shfl_xor(ka, o, 64); ko |= __shfl_xor(ko, o, 64); }
+        if (lane == 0) { L.hist[0][wave] = ka; L.hist[1][wave] = ko; }
+        __syncthreads();
+        ka = 0xFFFFFFFFu; ko = 0u;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { ka &= L.hist[0][w]; ko |= L.hist[1][w]; }
+        __syncthreads();
+        const uint32_t diff = ka ^ ko;
+        if (!diff) return;                                      // more than `head` identical scores: general path
+        int pos = 31 - __builtin_clz(diff);
+        uint32_t prefix = ka & ~((pos == 31) ? 0xFFFFFFFFu : ((2u << pos) - 1u));
+        uint32_t before = 0;
+        bool ok = false;
+        while (pos >= 0) {
+            const int lo = pos >= 7 ? pos - 7 : 0;
+            const uint32_t nbins = 1u << (pos - lo + 1);
+            const uint32_t hi_mask = pos == 31 ? 0u : ~((2u << pos) - 1u);
+            for (int i = tid; i < 16 * 256; i += EN_THREADS) (&L.hist[0][0])[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < EN2_HR; ++c) {
+                const uint32_t k = kreg[c];
+                if (k != 0xFFFFFFFFu && (k & hi_mask) == prefix) atomicAdd(&L.hist[wave][(k >> lo) & (nbins - 1u)], 1u);
+            }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t t = 0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) t += L.hist[w][tid];
+                L.tot[tid] = t;
+            }
+            __syncthreads();
+            if (wave == 0) {                                    // number of leading bins that fit into the window, and their total
+                const uint32_t t0 = L.tot[lane * 4], t1 = L.tot[lane * 4 + 1], t2 = L.tot[lane * 4 + 2], t3 = L.tot[lane * 4 + 3];
+                const uint32_t mine4 = t0 + t1 + t2 + t3;
+                uint32_t incl = mine4;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+                const uint32_t b0 = before + incl - mine4;      // candidates ranked before this lane's first bin
+                const uint32_t c0 = b0 + t0, c1 = c0 + t1, c2 = c1 + t2, c3 = c2 + t3;
+                const uint32_t fit = (c0 <= head ? 1u : 0u) + (c1 <= head ? 1u : 0u) + (c2 <= head ? 1u : 0u) + (c3 <= head ? 1u : 0u);
+                uint32_t nb = fit;                               // cumulative counts are monotone: fitting bins form a prefix
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) nb += __shfl_xor(nb, o, 64);
+                if ((uint32_t)lane == (nb ? (nb - 1) >> 2 : 0u)) {
+                    const uint32_t within = nb ? ((nb - 1) & 3u) : 0u;
+                    const uint32_t upto = nb == 0 ? before : (within == 0 ? c0 : within == 1 ? c1 : within == 2 ? c2 : c3);
+                    L.sel[0] = nb; L.sel[1] = upto;
+                }
+            }
+            __syncthreads();
+            const uint32_t nb = L.sel[0], upto = L.sel[1];      // bins [0, nb) fit; `upto` candidates are ranked below bin nb
+            if (upto >= head / 2 || nb >= nbins) {
+                key_star = prefix + (nb << lo) - 1u;            // every key below bin nb of this prefix range
+                ok = upto > 0 && nb < nbins;                    // (nb == nbins cannot happen while more than `head` keys are in range)
+                break;
+            }
+            before = upto;                                      // bin nb straddles the window: refine inside it
+            prefix |= nb << lo;
+            pos = lo - 1;
+            __syncthreads();
+        }
+        if (!ok) return;                                        // one score value shared by hundreds of candidates: general path
+    }
+    uint32_t n_le = 0, n;
+#pragma unroll
+    for (int c = 0; c < EN2_HR; ++c) n_le += (kreg[c] <= key_star) ? 1u : 0u;        // the sentinel ~0 is above every cut
+    uint32_t pos = block_excl_scan(n_le, L, n);
+#pragma unroll
+    for (int c = 0; c < EN2_HR; ++c)
+        if (kreg[c] <= key_star) { if (pos < (uint32_t)EN2_HEAD) tmpk[pos] = ((uint64_t)kreg[c] << 32) | freg[c]; ++pos; }
+    if (tid < EN2_HEAD) rank[tid] = 0;
+    __syncthreads();
+    n = n < (uint32_t)EN2_HEAD ? n : (uint32_t)EN2_HEAD;        // (n == head when cnt > head, else cnt)
+    {   // rank sort: thread (i, half) counts the keys of its half that precede key i; keys are distinct -> a permutation
+        const uint32_t i = tid & (EN2_HEAD - 1), half = tid >> 9;
+        if (i < n) {
+            const uint64_t ki = tmpk[i];
+            uint32_t r = 0;
+            const uint32_t j0 = half * (EN2_HEAD / 2), j1 = j0 + EN2_HEAD / 2 < n ? j0 + EN2_HEAD / 2 : n;
+            for (uint32_t j = j0; j < j1; ++j) r += tmpk[j] < ki ? 1u : 0u;
+            atomicAdd(&rank[i], r);
+        }
+    }
+    __syncthreads();
+    const float4* Bx = (const float4*)boxes + (size_t)b * A;
+    if (tid < (int)n) {
+        const uint64_t k = tmpk[tid];
+        const uint32_t r = rank[tid], flat = (uint32_t)k;
+        keys[r] = k;
+        sb[r] = Bx[flat / (uint32_t)nc];
+        scl[r] = (uint16_t)(flat % (uint32_t)nc);
+    }
+    __syncthreads();
+    int nk = 0;
+    for (uint32_t t0 = 0; t0 < n && nk < max_out; t0 += 64) {
+        const uint32_t j = t0 + lane;
+        const bool valid = j < n;
+        const float4 bj = valid ? sb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t cj = valid ? scl[j] : 0xFFFFu;
+        const float aj = box_area(bj);
+        uint64_t d = 0;
+        for (int k = wave; k < nk; k += 16) {
+            const float4 bk = kbox[k];
+            d |= __ballot(valid && (uint32_t)kcl[k] == cj && iou_f32(bk, box_area(bk), bj, aj) > iou_thr);
+        }
+        if (lane == 0) dead[wave] = d;
+        for (int i = wave; i < 64; i += 16) {
+            const uint32_t ji = t0 + i;
+            uint64_t m = 0;
+            if (ji < n) {
+                const float4 bi = sb[ji];
+                m = __ballot(valid && lane > i && (uint32_t)scl[ji] == cj && iou_f32(bi, box_area(bi), bj, aj) > iou_thr);
+            }
+            if (lane == 0) Mrow[i] = m;
+        }
+        __syncthreads();
+        uint64_t alive = __ballot(valid);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) alive &= ~dead[w];
+        const uint64_t myrow = Mrow[lane];
+        const uint32_t rlo = (uint32_t)myrow, rhi = (uint32_t)(myrow >> 32);
+        uint64_t keptmask = 0;
+        int nk2 = nk;
+        while (alive && nk2 < max_out) {
+            const int i = __builtin_ctzll(alive);
+            keptmask |= 1ull << i;
+            ++nk2;
+            const uint64_t row = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)rlo, i);
+            alive &= ~row;
+            alive &= ~(1ull << i);
+        }
+        if (wave == 0 && ((keptmask >> lane) & 1ull)) {
+            const int r = nk + __builtin_popcountll(keptmask & ((1ull << lane) - 1ull));
+            kbox[r] = bj; kcl[r] = (uint16_t)cj; kkey[r] = keys[j];
+        }
+        nk = nk2;
+        __syncthreads();
+    }
+    if (nk < max_out && cnt > n) return;                        // the head did not suffice: general path (done stays 0)
+    for (int i = tid; i < max_out; i += EN_THREADS) {
+        const size_t o = (size_t)b * max_out + i;
+        if (i < nk) {
+            ((float4*)out_boxes)[o] = kbox[i];
+            out_scores[o] = S[(uint32_t)kkey[i]];
+            out_labels[o] = (int32_t)kcl[i];
+        } else {
+            ((float4*)out_boxes)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+            out_scores[o] = 0.f;
+            out_labels[o] = 0;
+        }
+    }
+    if (tid == 0) { num_dets[b] = nk; ws.done[b] = 1u; }
+}
+
 // per-class greedy NMS over one image's candidate list.  TIER 0: classes with <= 1024 candidates (256 threads, 26 KB of LDS,
 // several workgroups per CU); TIER 1: up to 4096 (1024 threads).  Both are launched over the same (nc, B) grid and a
 // workgroup leaves at once when the class belongs to the other tier (the count is only known on the device).
@@ -622,7 +859,7 @@ __device__ __forceinline__ void en2_one_class(unsigned char* smem, const float* 
     uint32_t n_c;
     uint32_t n = ws.count[b];
     n = n < (uint32_t)K ? n : (uint32_t)K;
-    const uint64_t* list = ws.cand + (size_t)b * K;
+    const uint64_t* list = ws.cand + (size_t)b * ws.lcap;
     if (tid == 0) misc[0] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += THREADS) {
@@ -700,6 +937,7 @@ __global__ __launch_bounds__(256) void en2_class_small_kernel(const float* __res
                                                               int max_out, int K, En2Ws ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int c = blockIdx.x, b = blockIdx.y;
+    if (ws.done[b]) return;
     const uint32_t n_c = ws.ccount[(size_t)b * nc + c];
     if (n_c == 0 || n_c > 1024u) return;                       // nkept was zeroed by the memset node of this call
     en2_one_class<1024, 256>(smem, boxes, A, nc, c, b, iou_thr, max_out, K, ws);
@@ -712,6 +950,7 @@ __global__ __launch_bounds__(1024) void en2_class_large_kernel(const float* __re
     __shared__ uint32_t heavy[16];
     __shared__ uint32_t n_heavy;
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (ws.done[b]) return;
     if (tid == 0) n_heavy = 0;
     __syncthreads();
     for (int c = tid; c < nc; c += 1024)
@@ -729,6 +968,7 @@ __global__ __launch_bounds__(256) void en2_merge_kernel(const float* __restrict_
     uint64_t* keys = (uint64_t*)smem;                          // EN_MAXK
     __shared__ uint32_t tot_sh;
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (ws.done[b]) return;
     if (tid == 0) tot_sh = 0;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -964,23 +1204,35 @@ extern "C" int yv_efficient_nms(const float* boxes, const float* scores, int B, 
     return yv_launch_status();
 }
 
-static size_t en2_layout(int B, int nc, int max_out, int K, En2Ws* w, unsigned char* base, size_t* zero_bytes) {
-    // [count (B) | ccount (B*nc) | nkept (B*nc)] zeroed per call, then cand (B*K u64), kept (B*nc*max_out u64)
+// capacity of an image's candidate list: every candidate of ordinary score sets fits (the fast path then never re-reads the
+// scores), never less than pre_topk, never more than there are scores
+static int en2_lcap(int A, int nc, int K) {
+    const long long total = (long long)A * nc;
+    long long c = total < 16384 ? total : 16384;
+    if (c < K) c = K;
+    return (int)((c + 63) & ~63LL);
+}
+
+static size_t en2_layout(int B, int A, int nc, int max_out, int K, En2Ws* w, unsigned char* base, size_t* zero_bytes) {
+    // [count (B) | ccount (B*nc) | nkept (B*nc) | done (B)] zeroed per call, then cand (B*K u64), kept (B*nc*max_out u64)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_count = take((size_t)B * 4), o_cc = take((size_t)B * nc * 4), o_nk = take((size_t)B * nc * 4);
+    const size_t o_done = take((size_t)B * 4);
     if (zero_bytes) *zero_bytes = off;
-    const size_t o_cand = take((size_t)B * K * 8), o_kept = take((size_t)B * nc * max_out * 8);
+    const int lcap = en2_lcap(A, nc, K);
+    const size_t o_cand = take((size_t)B * lcap * 8), o_kept = take((size_t)B * nc * max_out * 8);
     if (w && base) {
         w->count = (uint32_t*)(base + o_count); w->ccount = (uint32_t*)(base + o_cc); w->nkept = (uint32_t*)(base + o_nk);
-        w->cand = (uint64_t*)(base + o_cand); w->kept = (uint64_t*)(base + o_kept);
+        w->done = (uint32_t*)(base + o_done);
+        w->cand = (uint64_t*)(base + o_cand); w->kept = (uint64_t*)(base + o_kept); w->lcap = lcap;
     }
     return off;
 }
 
 extern "C" size_t yv_efficient_nms_ws_bytes(int B, int A, int nc, int max_out, int pre_topk) {
     if (B <= 0 || A <= 0 || nc <= 0 || max_out <= 0 || pre_topk <= 0 || pre_topk > EN_MAXK) return 0;
-    return en2_layout(B, nc, max_out, pre_topk, nullptr, nullptr, nullptr);
+    return en2_layout(B, A, nc, max_out, pre_topk, nullptr, nullptr, nullptr);
 }
 
 extern "C" int yv_efficient_nms_ws(const float* boxes, const float* scores, int B, int A, int nc, float score_threshold,
@@ -995,13 +1247,15 @@ extern "C" int yv_efficient_nms_ws(const float* boxes, const float* scores, int 
     if (B > 65535 || nc > 65535) return YV_ERR_LIMIT;            // grid.y / grid.x
     En2Ws w;
     size_t zero_bytes = 0;
-    const size_t need = en2_layout(B, nc, max_out, pre_topk, &w, (unsigned char*)ws, &zero_bytes);
+    const size_t need = en2_layout(B, A, nc, max_out, pre_topk, &w, (unsigned char*)ws, &zero_bytes);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) return YV_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ws, 0, zero_bytes, st) != hipSuccess) return YV_ERR_LAUNCH;
     const int total = A * nc;
     const int chunks = (total + EN2_FT * EN2_FPT - 1) / (EN2_FT * EN2_FPT);
     hipLaunchKernelGGL(en2_filter_kernel, dim3(chunks, B), dim3(EN2_FT), 0, st, scores, total, nc, score_threshold, pre_topk, w);
+    hipLaunchKernelGGL(en2_head_kernel, dim3(B), dim3(EN_THREADS), (size_t)max_out * (16 + 8 + 2) + 16, st, boxes, scores, A, nc,
+                       score_threshold, iou_threshold, max_out, pre_topk, w, num_dets, out_boxes, out_scores, out_labels);
     hipLaunchKernelGGL(en2_select_kernel, dim3(B), dim3(EN_THREADS), 0, st, scores, A, nc, score_threshold, pre_topk, w);
     auto lds_of = [&](int cap, int nw) { return (size_t)cap * (8 + 16) + (size_t)max_out * 16 + 64 * 8 + (size_t)nw * 8 + 16; };
     const size_t lds0 = lds_of(1024, 4), lds1 = lds_of(EN_MAXK, 16);
