@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0        # bf16 dense, MI355X_MICROARCH.md chip table
+DOMINANT_KERNEL = "gemm_p8_kernel"       # what profiles/pmc_traffic.json must have been collected for
+ROUND_TAG = "r02"
 
 
 def _cpu_loop(imgs, yolo_sd, vit_sd, vit_name, crops, budget_s, max_images):
@@ -367,11 +369,16 @@ def main():
         from yvhip.dist import union_length
         busy = union_length((base_ev.elapsed_time(e0), base_ev.elapsed_time(e1)) for _, e0, e1 in recs)
         achieved = flops / (busy * 1e-3) / 1e12 if busy > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel come from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command
+        # (tools/profile_summary.py -> profiles/pmc_traffic.json).  The file names the kernel and the round it was collected
+        # for; anything else (other kernel, older round) is reported as null instead of a stale number.
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.dtype == "bf16" and not large:
             try:
-                traffic = json.load(open(pmc)).get("gemm_dma_bytes_per_launch")
+                tj = json.load(open(pmc))
+                if tj.get("kernel") == DOMINANT_KERNEL and tj.get("round") == ROUND_TAG:
+                    traffic = tj.get("bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -390,11 +397,13 @@ def main():
                        "schedule": "single stream" if runner is None else
                                    ("HIP streams: detector of batch i+1 (high priority) overlaps classifier of batch i" +
                                     ("" if args.no_split else "; classifier runs as two concurrent half-batches")),
-                       "weights": "random-init, seed 42"},
+                       "weights": "random-init, seed 42",
+                       "gemm": "persistent 8-phase kernel, tile height per launch" +
+                               ("" if runner is None else ", 208 of 256 CUs (the rest stay free for the concurrent streams)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS * (2.0 if args.dtype == "mxfp8" else 1.0),
                          "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_TFLOPS * (2.0 if args.dtype == "mxfp8" else 1.0)),
-                         "traffic": traffic if args.dtype == "bf16" and not large else None,
-                         "kernel": ("gemm_dma_kernel<128,128> (all ViT linears)" if args.dtype == "bf16" else
+                         "traffic": traffic,
+                         "kernel": ("gemm_p8_kernel (qkv / proj / fc1 / fc2) + gemm_dma_kernel<128,128> (patch-embed, head)" if args.dtype == "bf16" else
                                     "gemm_mx_kernel<128,128> (block linears, block-scaled MFMA peak) + gemm_dma_kernel (patch-embed, head)"),
                          "launches": n_launch,
                          "avg_launch_us": ms * 1e3 / max(n_launch, 1), "kernel_busy_ms_per_step": busy / max(len(sampled), 1), "instrumented_steps": len(sampled),

@@ -102,13 +102,29 @@ def _oracle_grads(sd, x, labels, name):
     return loss.detach(), logits.detach(), {k: v.grad for k, v in p.items()}
 
 
+def _relu_free_head(sd):
+    """Network_Wrapper.fc = ReLU -> Linear(1000,128) -> ReLU -> Linear(128,nc) (utils/utils.py:64-70).  With random weights a
+    handful of the 1000 + 128 pre-activations sit within bf16 noise of zero; whether the device's forward lands on the same
+    side as the fp32 oracle is a coin flip per unit, and ONE flipped hidden unit changes every upstream gradient by ~1/sqrt(128):
+    measured on identical kernels, the per-tensor gradient error against autograd then wanders between 3.5 % and 11 % with
+    the rounding of the forward (tests/diagnostics/attn_forms.py).  Shifting both pre-activations well above zero makes the
+    two ReLUs act as the identity on BOTH sides, so the comparison measures the kernels and not the coin flips; the masking
+    itself is pinned by test_gpu_train.py::test_head_bwd (random masks, 1e-5 against autograd)."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["model.head.bias"] += 8.0                      # feats ~ N(0, 1.4^2) + 8 > 0
+    sd["fc.1.weight"] *= 0.05
+    sd["fc.1.bias"] += 6.0                            # hidden ~ 6 +- 0.6 > 0
+    sd["fc.3.weight"] *= 0.1                          # logits stay O(1): the loss is not saturated
+    return sd
+
+
 def test_config2_vit_b16_trainer_vs_autograd():
     """BASELINE.json configs[2] model (ViT-B/16, 224 x 224) through VitTrainer forward + backward at R = 4 against fp32
     autograd of the oracle: logits rel-L2 <= 2e-2, loss within 2 %, and EVERY one of the 152 + 4 parameter gradients
     compared per tensor.  The error table is printed; the gate is the one the table supports (see GRAD_TOL)."""
     from yvhip.training import VitTrainer
     name, R = "vit_base_patch16_224", 4
-    sd = ov.init_wrapper_state(name, seed=21)
+    sd = _relu_free_head(ov.init_wrapper_state(name, seed=21))
     g = torch.Generator().manual_seed(R)
     x = (torch.rand(R, 3, 224, 224, generator=g) * 2 - 1).to(torch.bfloat16).float()
     labels = torch.randint(0, 5, (R,), generator=g, dtype=torch.int32)
@@ -133,10 +149,10 @@ def test_config2_vit_b16_trainer_vs_autograd():
 
 
 # per-tensor gradient gates of the ViT trainer tests (rel-L2 against fp32 autograd); see test_config2_* for the table
-# measured on MI355X (round 2): median 0.035, max 0.043 (blocks.9.norm2.weight) - bf16 storage of every activation and
-# activation gradient, not growing with depth; an indexing bug in any tensor shows up as O(1)
-GRAD_TOL = 6e-2
-GRAD_TOL_MEDIAN = 4.5e-2
+# with the ReLU coin flips of the wrapper head taken out (_relu_free_head) what remains is the bf16 storage of every activation
+# and activation gradient; measured on MI355X (round 2): median 0.0065, max 0.0123 (model.cls_token) over the 156 tensors
+GRAD_TOL = 2.5e-2
+GRAD_TOL_MEDIAN = 1.5e-2
 
 
 # ------------------------------------------------------------------------------------- configs[4]: YOLOv8m + ViT-L/16

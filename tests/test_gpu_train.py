@@ -135,7 +135,8 @@ def _oracle_grads(sd, x, labels, name):
 def test_trainer_gradients_vs_autograd(yv, name, R):
     from oracle import boxes as ob, vit as ov
     from yvhip.training import VitTrainer
-    sd = ov.init_wrapper_state(name, seed=21)
+    from test_gpu_configs import _relu_free_head      # ReLU coin flips of the wrapper head taken out (see its docstring)
+    sd = _relu_free_head(ov.init_wrapper_state(name, seed=21))
     g = torch.Generator().manual_seed(R)
     x = (torch.rand(R, 3, 224, 224, generator=g) * 2 - 1).to(torch.bfloat16).float()
     labels = torch.randint(0, 5, (R,), generator=g, dtype=torch.int32)
@@ -153,9 +154,8 @@ def test_trainer_gradients_vs_autograd(yv, name, R):
         worst[k] = rel_l2(got[k].cpu(), v)
     ranked = sorted(worst.items(), key=lambda kv: -kv[1])
     print(f"{name} R={R}: gradient rel-L2 vs fp32 autograd, worst: " + ", ".join(f"{k} {e:.3f}" for k, e in ranked[:4]))
-    bad = {k: e for k, e in worst.items() if e > 8e-2}
-    # bf16 forward (logit rel. error ~1e-2) moves dlogits and flips a few ReLU masks of the 1000-d head: the
-    # gradient error is a uniform 2-6 % per tensor (tests/diagnostics/grad_error_table.py), not growing with depth
+    bad = {k: e for k, e in worst.items() if e > 2e-2}
+    # what remains without the ReLU coin flips: bf16 storage noise of activations and activation gradients (measured <= 0.7 %)
     assert not bad, bad
 
 

@@ -33,7 +33,8 @@ thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;   // yv_s
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
 int g_opt_group_m = 8;
 int g_opt_staged = 1;
-int g_opt_p8 = 0;                  // persistent 8-phase 256x256 kernel for wide bf16-output linears (qkv, fc1): "linear_p8"
+int g_opt_p8 = 2;                  // persistent 8-phase kernel: 0 off, 1 wide bf16-output linears only (qkv, fc1), 2 every eligible
+                                   // linear incl. the f32 residual ones (proj, fc2): "linear_p8"
 std::mutex g_ws_mu;
 std::map<void*, std::pair<void*, size_t>> g_ws;   // per-stream split-K workspace (yv_set_workspace)
 static bool ws_lookup(void* stream, void** ws, size_t* bytes) {
@@ -90,19 +91,21 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// erf-form GELU (timm's nn.GELU, not the tanh form): erfc APPROXIMATED by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output step):
-//   w = 0.5*erfc(|x|/sqrt2) = t*(a1+t*(a2+...))*exp(-x^2/2),  t = 1/(1+p|x|/sqrt2)   (0.5 folded into a_i)
-//   gelu(x) = x*Phi(x) = max(x,0) - |x*w|
+// erf-form GELU through x * sigmoid(x * (p0 + p1 x^2 + p2 x^4)), coefficients fitted (minimax, |x| <= 8) against
+// 0.5 x (1 + erf(x / sqrt 2)): max abs error 2.5e-5 - below half a bf16 step of the output everywhere the output exceeds
+// 0.01 in magnitude.  x^2 is clamped at 64 (beyond |x| = 8 the result is x or 0 to f32 precision; the quartic would turn over).
 __device__ __forceinline__ float gelu_f(float x) {
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
-    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-    p = fmaf(p, t, 0.5f * 1.421413741f);
-    p = fmaf(p, t, 0.5f * -0.284496736f);
-    p = fmaf(p, t, 0.5f * 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);     // exp(-x^2/2)
-    return fmaxf(x, 0.0f) - fabsf(x * (p * t * e));
+    const float x2 = fminf(x * x, 64.0f);
+    float q = fmaf(-7.03039117e-4f * -1.4426950408889634f, x2, 7.40113286e-2f * -1.4426950408889634f);
+    q = fmaf(q, x2, 1.59501573f * -1.4426950408889634f);
+    const float e = __builtin_amdgcn_exp2f(x * q);                  // exp(-z)
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-// d/dx gelu(x) = Phi(x) + x * phi(x), same erfc approximation as gelu_f
+
+// (round 1 evaluated erfc by Abramowitz-Stegun 7.1.26: 14 operations per value against 9 here.  ONE definition for every forward
+// kernel: schedules that route a linear through different kernels - full batch vs half batches - must agree bit for bit.)
+// d/dx gelu(x) = Phi(x) + x * phi(x) of the erf form (erfc by Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7); the forward's
+// sigmoid fit differs from the erf form by <= 2.5e-5, i.e. this is its derivative to ~1e-4
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
     float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
@@ -1095,17 +1098,6 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs g) {
 // Restrictions (checked by the host, everything else takes the 128 x 128 kernel): N % 256 == 0, N <= 4096, K % 64 == 0,
 // bf16 output, flags within {BIAS, GELU}, operand images below 2 GB.
 // ---------------------------------------------------------------------------------------------
-// erf-form GELU through x * sigmoid(x * (p0 + p1 x^2 + p2 x^4)), coefficients fitted (minimax, |x| <= 8) against
-// 0.5 x (1 + erf(x / sqrt 2)): max abs error 2.5e-5 - below half a bf16 step of the output everywhere the output exceeds
-// 0.01 in magnitude.  x^2 is clamped at 64 (beyond |x| = 8 the result is x or 0 to f32 precision; the quartic would turn over).
-__device__ __forceinline__ float gelu_fast_f(float x) {
-    const float x2 = fminf(x * x, 64.0f);
-    float q = fmaf(-7.03039117e-4f * -1.4426950408889634f, x2, 7.40113286e-2f * -1.4426950408889634f);
-    q = fmaf(q, x2, 1.59501573f * -1.4426950408889634f);
-    const float e = __builtin_amdgcn_exp2f(x * q);                  // exp(-z)
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
 typedef __attribute__((address_space(3))) void* lds_void_t;
 
 // MF0 / MF1: 16-row activation fragments per wave group in the first / second half of its rows; tile = 32 (MF0 + MF1) rows x
@@ -1320,7 +1312,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                         const float4 bvi = *(const float4*)(bl + i * 16);
                         float v0 = acc[i][j][0] + bvi.x, v1 = acc[i][j][1] + bvi.y;
                         float v2 = acc[i][j][2] + bvi.z, v3 = acc[i][j][3] + bvi.w;
-                        if (gelu) { v0 = gelu_fast_f(v0); v1 = gelu_fast_f(v1); v2 = gelu_fast_f(v2); v3 = gelu_fast_f(v3); }
+                        if (gelu) { v0 = gelu_f(v0); v1 = gelu_f(v1); v2 = gelu_f(v2); v3 = gelu_f(v3); }
                         const int c16 = i * 2 + (fq >> 1);
                         *(uint2*)(slab + fr * 128 + ((c16 ^ (fr & 7)) << 4) + (fq & 1) * 8) =
                             make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));

@@ -139,8 +139,16 @@ class PipelinedRunner:
     unlucky pair vs 8.61 ms with the priority split; a lucky pair gives the same 8.6-8.9 ms)."""
 
     def __init__(self, pipe: DetectClassifyPipeline, split_classifier=False, run_ahead: int = 1,
-                 det_priority: int = -1):
+                 det_priority: int = -1, gemm_cus: Optional[int] = 208):
+        """gemm_cus: workgroups of the persistent classifier GEMMs (yv_set_option "linear_p8_cus", PROCESS-WIDE, set here and
+        left in place).  Those workgroups own a CU each for a whole launch (160 KB of LDS, 256 VGPRs x 8 waves), so with all
+        256 CUs taken the kernels of the other streams (detector, the other half-batch's LayerNorm / attention) can only
+        start when a GEMM ends; leaving 48 CUs free lets them run alongside: 8.07 -> 7.75 ms per step measured (208 and 200
+        equal, 224 7.85, 192 and below worse again).  None keeps the library default (every CU)."""
         self.pipe = pipe
+        if gemm_cus is not None:
+            from . import set_option
+            set_option("linear_p8_cus", int(gemm_cus))
         self.run_ahead = max(int(run_ahead), 1)                    # batches the detect stream may lead the classifier by
         self.s_det = torch.cuda.Stream(priority=det_priority)
         self.s_cls = torch.cuda.Stream()
