@@ -33,6 +33,9 @@ for name, m, n, k in shapes:
             for gm in groups:
                 yvhip.set_option("linear_variant", 9 if v >= 900 else v); yvhip.set_option("linear_group_m", gm)
                 yvhip.set_option("linear_p8_rows", v - 900 if v >= 900 else 0)      # 9xx: persistent kernel with xx0.. rows forced
+                yvhip.set_option("linear_p8_sched", 1 if v == 91 else 0)
+                if v == 91:
+                    yvhip.set_option("linear_variant", 9)                            # 91: persistent kernel, XCD-contiguous schedule
                 out.zero_()
                 yvhip.linear(a, w, bias, out, flags=flags)
                 torch.cuda.synchronize()

@@ -84,6 +84,8 @@ struct GemmArgs {
     int splitk;                  // conv only: K range split over `splitk` workgroups per tile (partials in `partial`)
     float* partial;              // (splitk, M, N) f32
     int staged;                  // coalesced LDS-staged epilogue usable (alignment / width checked on the host)
+    int sched;                   // gemm_p8: 0 = the grid strides through the tile sequence round by round, 1 = one contiguous
+                                 //          share of the sequence per XCD
     uint8_t* mxq;                // YV_EPI_OUT_MXFP8: e4m3 image of the output (row stride ldmxq bytes) ...
     long long ldmxq;
     uint8_t* mxs;                // ... and its E8M0 block scales, K-step-major (N/128, mx_rows, 4)
@@ -1121,15 +1123,25 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = g.N >> 8;
     const int ntiles = tiles_m * tiles_n;
     const int G = gridDim.x;
-    // position of this block inside a round of G blocks: XCD x (= blockIdx & 7 under round-robin placement, speed only) walks a
-    // contiguous chunk of the round's tile sequence
-    int bpos;
-    {
+    // tile schedule (blockIdx & 7 = XCD under round-robin placement - speed only, never correctness): see GemmArgs::sched
+    int Lx, seq0, seq1, lid;
+    if (g.sched == 1) {
+        const int nx = G < 8 ? G : 8;                           // (grids smaller than 8 blocks: one sequence share per block)
+        const int xcd = (int)blockIdx.x % nx;
+        lid = (int)blockIdx.x / nx;
+        Lx = (G - xcd + nx - 1) / nx;                           // blocks that share this part of the sequence
+        int cum = 0;                                            // blocks of the parts before this one
+        for (int y = 0; y < xcd; ++y) cum += (G - y + nx - 1) / nx;
+        // parts proportional to their block counts: with tiles == blocks every block gets exactly one tile (equal parts would
+        // hand a 29-block XCD 30 tiles and double the launch time)
+        seq0 = (int)((long long)ntiles * cum / G); seq1 = (int)((long long)ntiles * (cum + Lx) / G);
+    } else {
+        // round r covers sequence positions [r G, r G + G); inside a round XCD x walks a contiguous chunk of it
         const int q = G >> 3, r = G & 7, x = blockIdx.x & 7;
-        bpos = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);
+        Lx = G; seq0 = 0; seq1 = ntiles;
     }
-    if (bpos >= ntiles) return;
-
+    if (seq0 + lid >= seq1) return;
     {   // bias -> LDS once (plain loads, before any DMA is in flight)
         float* bl = (float*)(smem + BIAS0);
         for (int i = tid; i < g.N; i += 512) bl[i] = (g.flags & YV_EPI_BIAS) ? g.bias[i] : 0.0f;
@@ -1184,11 +1196,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 
     const int nk = g.K / BK;
     uint32_t ocur[4][2], onxt[4][2];
-    int seq = bpos, m0, n0, m0n = 0, n0n = 0;
+    int seq = seq0 + lid, m0, n0, m0n = 0, n0n = 0;
     coords(seq, m0, n0);
     set_offsets(ocur, m0, n0);
-    bool has_next = seq + G < ntiles;
-    if (has_next) { coords(seq + G, m0n, n0n); set_offsets(onxt, m0n, n0n); }
+    bool has_next = seq + Lx < seq1;
+    if (has_next) { coords(seq + Lx, m0n, n0n); set_offsets(onxt, m0n, n0n); }
     int gk = 0;                                                // K tiles consumed so far by this workgroup (stage = gk & 1)
 
     // half-tile `kind` of K tile t of the CURRENT tile into stage `st` / of K tile tt of the NEXT tile (separate functions:
@@ -1385,12 +1397,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             }
         }
         if (!has_next) break;
-        seq += G;
+        seq += Lx;
         m0 = m0n; n0 = n0n;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ocur[k][0] = onxt[k][0]; ocur[k][1] = onxt[k][1]; }
-        has_next = seq + G < ntiles;
-        if (has_next) { coords(seq + G, m0n, n0n); set_offsets(onxt, m0n, n0n); }
+        has_next = seq + Lx < seq1;
+        if (has_next) { coords(seq + Lx, m0n, n0n); set_offsets(onxt, m0n, n0n); }
     }
     if (wm == 0) bar();                                        // group 0 waits for group 1's last barrier
 }
@@ -1424,6 +1436,7 @@ int launch_p8_inst(GemmArgs& g, hipStream_t st, int n_cu) {
     return launch_p8_inst2<MF0, MF1, false>(g, st, n_cu);
 }
 
+int g_opt_p8_sched = 1;            // tile schedule of the persistent kernel (GemmArgs::sched): "linear_p8_sched"
 int g_opt_p8_cus = 0;              // persistent grid size; 0 = every CU ("linear_p8_cus": leave CUs to concurrent streams)
 int g_opt_p8_rows = 0;             // 0 = pick the tile height per launch; 128 / 160 / 192 / 224 / 256 force it ("linear_p8_rows")
 
@@ -1435,6 +1448,7 @@ int launch_p8(GemmArgs& g, hipStream_t st) {
         n_cu_dev = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int n_cu = (g_opt_p8_cus > 0 && g_opt_p8_cus < n_cu_dev) ? g_opt_p8_cus : n_cu_dev;
+    g.sched = g_opt_p8_sched;
     // tile height: minimise rounds x (rows + a fixed per-tile cost worth ~24 rows: epilogue, pipeline turn-around)
     int best = 256;
     if (g_opt_p8_rows) {
@@ -1749,6 +1763,7 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!strcmp(key, "linear_p8")) { g_opt_p8 = value; return YV_OK; }
     if (!strcmp(key, "linear_p8_rows")) { g_opt_p8_rows = value; return YV_OK; }
     if (!strcmp(key, "linear_p8_cus")) { g_opt_p8_cus = value; return YV_OK; }
+    if (!strcmp(key, "linear_p8_sched")) { g_opt_p8_sched = value; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_splitk")) { g_opt_linear_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_wide_min_n")) { g_opt_wide_min = value; return YV_OK; }
