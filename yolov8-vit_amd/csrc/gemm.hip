@@ -1408,193 +1408,6 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// gemm_p4_kernel: 256 x 256 tile, FOUR waves (one per SIMD) of 128 x 128 each, 256 accumulator + ~170 operand registers per lane
-// (the unified file has 512).  Why: in the 8-wave kernel the four column-group waves re-read the same activation rows from
-// LDS (192 KB of fragment reads per 64-deep K tile per CU) and a K tile costs 8 barriers; its K tile takes ~4,100 cycles for
-// 2,048 cycles of MFMA per SIMD.  Here a K tile reads 128 KB of fragments, has ONE barrier, and every wave runs 128 MFMAs per
-// K tile back to back with the fragment reads of the NEXT half K tile and the DMA of the K tile after next issued in their
-// shadow (operand sets alternate between the two 32-deep halves of a K tile):
-//     per K tile t (stage t & 1):
-//       [vmcnt(0): my DMA pieces of K tile t+1 landed]  barrier  (also: everyone has read all of stage t & 1)
-//       phase B: issue the 16 DMA pieces of K tile t+2 into stage t & 1 | read fragments (t+1, k half 0) | 64 MFMAs (t, k half 1)
-//       phase A: read fragments (t+1, k half 1)                                                        | 64 MFMAs (t+1, k half 0)
-// The tile loop is persistent with the same cross-tile prefetch, slab epilogue, bias-in-LDS and XCD schedule as gemm_p8_kernel.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_p4_kernel(GemmArgs g) {
-    constexpr int A_BYTES = 256 * 128, W_BYTES = 256 * 128, STAGE = A_BYTES + W_BYTES;
-    constexpr int SLAB0 = 2 * STAGE, SLAB = 4096, BIAS0 = SLAB0 + 4 * SLAB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int M = g.M;
-    if (g.m_dev) { long long md = (long long)g.m_dev[0] * g.m_mul; M = md < M ? (int)md : M; }
-    const int tiles_m = (M + 255) >> 8, tiles_n = g.N >> 8;
-    const int ntiles = tiles_m * tiles_n;
-    const int G = gridDim.x;
-    int Lx, seq0, seq1, lid;
-    {
-        const int nx = G < 8 ? G : 8;
-        const int xcd = (int)blockIdx.x % nx;
-        lid = (int)blockIdx.x / nx;
-        Lx = (G - xcd + nx - 1) / nx;
-        int cum = 0;
-        for (int y = 0; y < xcd; ++y) cum += (G - y + nx - 1) / nx;
-        seq0 = (int)((long long)ntiles * cum / G); seq1 = (int)((long long)ntiles * (cum + Lx) / G);
-    }
-    if (seq0 + lid >= seq1) return;
-    {
-        float* bl = (float*)(smem + BIAS0);
-        for (int i = tid; i < g.N; i += 256) bl[i] = (g.flags & YV_EPI_BIAS) ? g.bias[i] : 0.0f;
-    }
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.a0, 0, (int)(((long long)(g.M - 1) * g.lda0 + g.K) * 2), 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (int)((long long)g.N * g.K * 2), 0x00020000);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int wrow_m = wm * 128, wrow_n = wn * 128;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int lrow = lane >> 3, lch = lane & 7;
-    auto coords = [&](int seq, int& m0, int& n0) __attribute__((always_inline)) {
-        const int GM = g.group_m, per = GM * tiles_n;
-        const int grp = seq / per, first = grp * GM;
-        const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
-        const int in = seq - grp * per;
-        m0 = (first + in % gsz) << 8;
-        n0 = (in / gsz) << 8;
-    };
-    // DMA pieces: piece p (0..31) of an operand tile = rows 8p..8p+7; wave w issues pieces w, w+4, ... (8 per operand per K tile).
-    // One per-lane offset per operand (piece q adds a wave-uniform q * 32 rows, carried in the instruction's scalar offset);
-    // rows past the end of A lie beyond the descriptor's range and read as zeros.
-    const int strideA = 32 * g.lda0 * 2, strideW = 32 * g.K * 2;
-    auto set_offsets = [&](uint32_t& oa_, uint32_t& ow_, int m0, int n0) __attribute__((always_inline)) {
-        const int r = wave * 8 + lrow;
-        oa_ = (uint32_t)(((long long)(m0 + r) * g.lda0 + ((lch ^ (r & 7)) << 3)) * 2);
-        ow_ = (uint32_t)(((long long)(n0 + r) * g.K + ((lch ^ (r & 7)) << 3)) * 2);
-    };
-    const int nk = g.K / BK;
-    uint32_t oa, ow, oan = 0, own = 0;
-    int seq = seq0 + lid, m0, n0, m0n = 0, n0n = 0;
-    coords(seq, m0, n0);
-    set_offsets(oa, ow, m0, n0);
-    bool has_next = seq + Lx < seq1;
-    if (has_next) { coords(seq + Lx, m0n, n0n); set_offsets(oan, own, m0n, n0n); }
-
-    auto issue_cur = [&](int t, int st) __attribute__((always_inline)) {            // all 16 pieces of K tile t of the current tile
-        unsigned char* base = smem + (st & 1) * STAGE;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t)(base + (q * 4 + wave) * 1024), 16, (int)oa, t * 128 + q * strideA, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t)(base + A_BYTES + (q * 4 + wave) * 1024), 16, (int)ow, t * 128 + q * strideW, 0, 0);
-        }
-    };
-    auto issue_nxt = [&](int tt, int st) __attribute__((always_inline)) {
-        if (!has_next) return;
-        unsigned char* base = smem + (st & 1) * STAGE;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t)(base + (q * 4 + wave) * 1024), 16, (int)oan, tt * 128 + q * strideA, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t)(base + A_BYTES + (q * 4 + wave) * 1024), 16, (int)own, tt * 128 + q * strideW, 0, 0);
-        }
-    };
-    f32x4 acc[8][8];                                            // [weight fragment i][activation fragment j]
-    bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];                      // operand sets of the two 32-deep halves of a K tile
-    auto read_set = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[8], int st, int ks) __attribute__((always_inline)) {
-        const unsigned char* A = smem + (st & 1) * STAGE;
-        const unsigned char* W = A + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ra = wrow_m + j * 16 + fr, rw = wrow_n + j * 16 + fr;
-            fa[j] = *(const bf16x8*)(A + ra * 128 + (((ks * 4 + fq) ^ (ra & 7)) << 4));
-            fw[j] = *(const bf16x8*)(W + rw * 128 + (((ks * 4 + fq) ^ (rw & 7)) << 4));
-        }
-    };
-    auto mma_set = [&](const bf16x8 (&fa)[8], const bf16x8 (&fw)[8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-    };
-
-    __syncthreads();                                           // bias image complete
-    // prologue: K tiles 0 and 1 of the first tile in flight; K tile 0 landed; its first operand set in registers
-    issue_cur(0, 0);
-    issue_cur(1, 1);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // my 16 pieces of K tile 0
-    bar();
-    read_set(fa0, fw0, 0, 0);
-    int gk = 0;                                                 // running K-tile counter (stage = gk & 1)
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < nk; ++t, ++gk) {
-            // phase A: second operand set of K tile t | MFMAs of its first half
-            read_set(fa1, fw1, gk, 1);
-            mma_set(fa0, fw0);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // K tile t+1 (mine) landed; stage gk & 1 fully read (by me)
-            __builtin_amdgcn_sched_barrier(0);
-            bar();
-            __builtin_amdgcn_sched_barrier(0);
-            // phase B: DMA of K tile t+2 into the stage just released | first operand set of K tile t+1 | MFMAs of the second half
-            if (t + 2 < nk) issue_cur(t + 2, gk);
-            else issue_nxt(t + 2 - nk, gk);
-            if (t + 1 < nk || has_next) read_set(fa0, fw0, gk + 1, 0);
-            mma_set(fa1, fw1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- epilogue (bf16 output): 16 rows x 128 columns per pass through this wave's 4 KB slab ----
-        {
-            unsigned char* slab = smem + SLAB0 + wave * SLAB;
-            const float* bl = (const float*)(smem + BIAS0) + n0 + wrow_n + fq * 4;
-            const bool gelu = g.flags & YV_EPI_GELU;
-            uint16_t* outp = (uint16_t*)g.out;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float4 bvi = *(const float4*)(bl + i * 16);
-                    float v0 = acc[i][j][0] + bvi.x, v1 = acc[i][j][1] + bvi.y;
-                    float v2 = acc[i][j][2] + bvi.z, v3 = acc[i][j][3] + bvi.w;
-                    if (gelu) { v0 = gelu_f(v0); v1 = gelu_f(v1); v2 = gelu_f(v2); v3 = gelu_f(v3); }
-                    const int c16 = i * 2 + (fq >> 1);          // 16 chunks of 16 B per 256-byte row
-                    *(uint2*)(slab + fr * 256 + ((c16 ^ fr) << 4) + (fq & 1) * 8) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = it * 4 + (lane >> 4), ch = lane & 15;
-                    const int m = m0 + wrow_m + j * 16 + row;
-                    const uint4 pk = *(const uint4*)(slab + row * 256 + ((ch ^ row) << 4));
-                    if (m < M) *(uint4*)(outp + (long long)m * g.ldo + n0 + wrow_n + ch * 8) = pk;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        }
-        if (!has_next) break;
-        seq += Lx;
-        m0 = m0n; n0 = n0n;
-        oa = oan; ow = own;
-        has_next = seq + Lx < seq1;
-        if (has_next) { coords(seq + Lx, m0n, n0n); set_offsets(oan, own, m0n, n0n); }
-    }
-}
-
-int launch_p4(GemmArgs& g, hipStream_t st, int n_cu) {
-    g.tiles_m = (g.M + 255) / 256;
-    g.tiles_n = g.N / 256;
-    const size_t lds = 2 * 65536 + 4 * 4096 + 16384;
-    if (hipFuncSetAttribute((const void*)gemm_p4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return YV_ERR_LAUNCH;
-    const int tiles = g.tiles_m * g.tiles_n;
-    const int grid = tiles < n_cu ? tiles : n_cu;
-    if (t_time_start || t_time_stop) {
-        hipExtLaunchKernelGGL(gemm_p4_kernel, dim3(grid), dim3(256), (uint32_t)lds, st, t_time_start, t_time_stop, 0, g);
-        t_time_start = t_time_stop = nullptr;
-    } else {
-        hipLaunchKernelGGL(gemm_p4_kernel, dim3(grid), dim3(256), lds, st, g);
-    }
-    return yv_launch_status();
-}
-
 template <int MF0, int MF1, bool F32OUT>
 int launch_p8_inst2(GemmArgs& g, hipStream_t st, int n_cu) {
     constexpr int BM = 32 * (MF0 + MF1);
@@ -1654,7 +1467,6 @@ int launch_p8(GemmArgs& g, hipStream_t st) {
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand[c]; }
         }
     }
-    if (g_opt_variant == 12 && !(g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32))) return launch_p4(g, st, n_cu);
     switch (best) {
         case 224: return launch_p8_inst<4, 3>(g, st, n_cu);
         case 192: return launch_p8_inst<3, 3>(g, st, n_cu);
@@ -2015,7 +1827,6 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
             case 4: return launch_dma<128, 256, 2, 4>(g, stream);
             case 8: return launch_8phase(g, stream);
             case 9: return launch_p8(g, stream);
-            case 12: return p8_ok ? launch_p8(g, stream) : launch_dma<128, 128, 2, 2>(g, stream);   // 4-wave form inside launch_p8
             case 201: return launch_dma<256, 256, 2, 4, 1>(g, stream);
             case 202: return launch_dma<256, 256, 2, 4, 2>(g, stream);
             case 203: return launch_dma<256, 256, 2, 4, 3>(g, stream);
