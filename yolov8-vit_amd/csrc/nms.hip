@@ -363,7 +363,7 @@ struct En2Ws {                              // device pointers into the caller's
     uint32_t* count;                        // (B)      candidates of the image (may exceed pre_topk)
     uint32_t* ccount;                       // (B, nc)  candidates per class (of the selected set)
     uint32_t* nkept;                        // (B, nc)
-    uint32_t* done;                         // (B)      1: en2_head_kernel produced the image's final outputs
+    uint32_t* done;                         // (B)      1: the head produced the image's final outputs
 };
 
 __device__ __forceinline__ float key_score(uint32_t key) {          // inverse of desc_key
@@ -522,14 +522,11 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, SelLds& L, ui
     return before + incl - mine;
 }
 
-__global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __restrict__ scores, int A, int nc,
-                                                                float score_thr, int K, En2Ws ws) {
-    __shared__ SelLds L;
-    __shared__ uint32_t cc[EN2_CC_LDS];
+__device__ __forceinline__ void en2_select_body(const float* __restrict__ scores, int A, int nc, float score_thr, int K,
+                                                const En2Ws& ws, int b, SelLds& L, uint32_t* cc) {
     uint32_t (&wave_cnt)[16] = L.wave_cnt;
     uint32_t (&sel)[4] = L.sel;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (ws.done[b] || ws.count[b] <= (uint32_t)K) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int total = A * nc;
     const float* S = scores + (size_t)b * total;
     const int chunks = (total + EN_THREADS - 1) / EN_THREADS;
@@ -642,40 +639,79 @@ __global__ __launch_bounds__(EN_THREADS) void en2_select_kernel(const float* __r
 // the suppression predicate, and stop at max_out kept.  If max_out boxes were kept - or every candidate of the image was in
 // the head - the result IS the sequential result and the image is marked done; otherwise (heavy suppression, ties on the
 // head's cut key, more than 45K scores) the general kernels below redo the image from scratch.
-constexpr int EN2_HEAD = 512;
+// Greedy resolution of one 64-candidate tile in parallel rounds (every wave runs it redundantly, uniform control flow).
+// alive: candidates no box kept in an earlier tile suppresses (uniform); col: the members i < lane of the tile that would
+// suppress this lane's candidate; room: how many boxes may still be kept.  Candidate j is kept iff it is alive and no KEPT
+// i < j suppresses it.  Per round every undecided candidate with a kept suppressor dies and every one whose suppressors are
+// all decided is kept - the lowest undecided one always can - so the loop takes (longest suppression chain) rounds, 2-4 on
+// detector output, instead of one scalar step per kept box.  The scan stops at max_out: only the first `room` kept count.
+__device__ __forceinline__ uint64_t tile_resolve(uint64_t alive, uint64_t col, int room) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t me = 1ull << lane;
+    uint64_t und = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(alive >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)alive);
+    uint64_t kept = 0;
+    while (und) {
+        const bool mine = (und & me) != 0;
+        const bool die = mine && (col & kept) != 0;
+        const bool keep = mine && !die && (col & und) == 0;
+        const uint64_t k = __ballot(keep), d = __ballot(die);
+        kept |= k;
+        und &= ~(k | d);
+    }
+    if (__builtin_popcountll(kept) > room)
+        kept = __ballot((kept & me) != 0 && __builtin_popcountll(kept & (me - 1ull)) < room);
+    return kept;
+}
+
+constexpr int EN2_HEAD = 512;                // capacity of the head: images with this many candidates or fewer are taken whole
+constexpr int EN2_WIN = 320;                 // otherwise a prefix of EN2_WIN/2 .. EN2_WIN members (rank sort cost grows with its square)
 constexpr int EN2_HR = 16;                  // candidate keys per thread held by en2_head_kernel (16 x 1024 = the list capacity)
-__global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                              int A, int nc, float score_thr, float iou_thr, int max_out, int K,
-                                                              En2Ws ws, int32_t* __restrict__ num_dets,
-                                                              float* __restrict__ out_boxes, float* __restrict__ out_scores,
-                                                              int32_t* __restrict__ out_labels) {
-    __shared__ SelLds L;
+__device__ __forceinline__ bool en2_head_body(const float* __restrict__ boxes, const float* __restrict__ scores, int A, int nc,
+                                              float iou_thr, int max_out, int K, const En2Ws& ws, int b, uint32_t& cnt,
+                                              SelLds& L, unsigned char* dyn, int32_t* __restrict__ num_dets,
+                                              float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                              int32_t* __restrict__ out_labels) {
     __shared__ uint64_t keys[EN2_HEAD];                        // unordered, then sorted
     __shared__ uint64_t tmpk[EN2_HEAD];
     __shared__ uint32_t rank[EN2_HEAD];
     __shared__ float4 sb[EN2_HEAD];
     __shared__ uint16_t scl[EN2_HEAD];
-    __shared__ uint64_t Mrow[64];
+    __shared__ uint64_t Mcol[2][64];                           // in-tile suppressor masks, double-buffered over tiles
     __shared__ uint64_t dead[16];
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];     // kept boxes (max_out float4), classes, keys
-    float4* kbox = (float4*)dyn;
+    float4* kbox = (float4*)dyn;                               // kept boxes (max_out float4), keys, classes
     uint64_t* kkey = (uint64_t*)(kbox + max_out);
     uint16_t* kcl = (uint16_t*)(kkey + max_out);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int total = A * nc;
     const float* S = scores + (size_t)b * total;
-    // the image's candidates were compacted by en2_filter_kernel (launched before this kernel): up to 16 of them per thread
-    const uint32_t cnt = ws.count[b];
-    if (cnt > (uint32_t)ws.lcap || cnt > (uint32_t)(EN2_HR * EN_THREADS)) return;      // done stays 0: general path
+    // the image's candidates were compacted into its list by en2_filter_kernel (the launch before): up to 16 per thread.
+    // The first half of the registers is fetched before the count is known (the workspace is readable up to lcap whatever it
+    // holds): one global round trip instead of two on the kernel's critical path.
     const uint64_t* list = ws.cand + (size_t)b * ws.lcap;
+    uint64_t raw[EN2_HR];
+#pragma unroll
+    for (int c = 0; c < EN2_HR / 2; ++c) {
+        const uint32_t i = (uint32_t)(c * EN_THREADS + tid);
+        raw[c] = i < (uint32_t)ws.lcap ? list[i] : ~0ull;
+    }
+    for (int i = tid; i < 16 * 256; i += EN_THREADS) (&L.hist[0][0])[i] = 0;     // (for the first histogram pass, under the loads)
+    cnt = ws.count[b];
+    if (cnt > (uint32_t)ws.lcap || cnt > (uint32_t)(EN2_HR * EN_THREADS)) return false;      // general path
+#pragma unroll
+    for (int c = EN2_HR / 2; c < EN2_HR; ++c) {
+        const uint32_t i = (uint32_t)(c * EN_THREADS + tid);
+        raw[c] = i < cnt ? list[i] : ~0ull;
+    }
     uint32_t kreg[EN2_HR], freg[EN2_HR];
 #pragma unroll
     for (int c = 0; c < EN2_HR; ++c) {
-        const uint32_t i = (uint32_t)(c * EN_THREADS + tid);
-        kreg[c] = 0xFFFFFFFFu; freg[c] = 0;
-        if (i < cnt) { const uint64_t k = list[i]; kreg[c] = (uint32_t)(k >> 32); freg[c] = (uint32_t)k; }
+        const bool in = (uint32_t)(c * EN_THREADS + tid) < cnt;
+        kreg[c] = in ? (uint32_t)(raw[c] >> 32) : 0xFFFFFFFFu;
+        freg[c] = in ? (uint32_t)raw[c] : 0u;
     }
     const uint32_t head = (uint32_t)(K < EN2_HEAD ? K : EN2_HEAD);
+    const uint32_t win = head < (uint32_t)EN2_WIN ? head : (uint32_t)EN2_WIN;     // prefix size aimed at when a cut is needed
     uint32_t key_star = 0xFFFFFFFEu;                            // take every candidate
     if (cnt > head) {
         // ANY prefix of the ranking with between head/2 and head members will do, so the cut is put on a radix-digit boundary:
@@ -687,24 +723,26 @@ __global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __res
             if (kreg[c] != 0xFFFFFFFFu) { ka &= kreg[c]; ko |= kreg[c]; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { ka &= __shfl_xor(ka, o, 64); ko |= __shfl_xor(ko, o, 64); }
-        if (lane == 0) { L.hist[0][wave] = ka; L.hist[1][wave] = ko; }
+        if (lane == 0) { L.tot[wave] = ka; L.tot[16 + wave] = ko; }      // (not L.hist: zeroed above for the first pass)
         __syncthreads();
         ka = 0xFFFFFFFFu; ko = 0u;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) { ka &= L.hist[0][w]; ko |= L.hist[1][w]; }
-        __syncthreads();
+        for (int w = 0; w < 16; ++w) { ka &= L.tot[w]; ko |= L.tot[16 + w]; }
         const uint32_t diff = ka ^ ko;
-        if (!diff) return;                                      // more than `head` identical scores: general path
+        if (!diff) return false;                                     // more than `head` identical scores: general path
         int pos = 31 - __builtin_clz(diff);
         uint32_t prefix = ka & ~((pos == 31) ? 0xFFFFFFFFu : ((2u << pos) - 1u));
         uint32_t before = 0;
-        bool ok = false;
+        bool ok = false, first = true;
         while (pos >= 0) {
             const int lo = pos >= 7 ? pos - 7 : 0;
             const uint32_t nbins = 1u << (pos - lo + 1);
             const uint32_t hi_mask = pos == 31 ? 0u : ~((2u << pos) - 1u);
-            for (int i = tid; i < 16 * 256; i += EN_THREADS) (&L.hist[0][0])[i] = 0;
-            __syncthreads();
+            if (!first) {                                       // (zeroed at kernel entry for the first pass)
+                for (int i = tid; i < 16 * 256; i += EN_THREADS) (&L.hist[0][0])[i] = 0;
+                __syncthreads();
+            }
+            first = false;
 #pragma unroll
             for (int c = 0; c < EN2_HR; ++c) {
                 const uint32_t k = kreg[c];
@@ -726,7 +764,7 @@ __global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __res
                 for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
                 const uint32_t b0 = before + incl - mine4;      // candidates ranked before this lane's first bin
                 const uint32_t c0 = b0 + t0, c1 = c0 + t1, c2 = c1 + t2, c3 = c2 + t3;
-                const uint32_t fit = (c0 <= head ? 1u : 0u) + (c1 <= head ? 1u : 0u) + (c2 <= head ? 1u : 0u) + (c3 <= head ? 1u : 0u);
+                const uint32_t fit = (c0 <= win ? 1u : 0u) + (c1 <= win ? 1u : 0u) + (c2 <= win ? 1u : 0u) + (c3 <= win ? 1u : 0u);
                 uint32_t nb = fit;                               // cumulative counts are monotone: fitting bins form a prefix
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) nb += __shfl_xor(nb, o, 64);
@@ -738,7 +776,7 @@ __global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __res
             }
             __syncthreads();
             const uint32_t nb = L.sel[0], upto = L.sel[1];      // bins [0, nb) fit; `upto` candidates are ranked below bin nb
-            if (upto >= head / 2 || nb >= nbins) {
+            if (upto >= win / 2 || nb >= nbins) {
                 key_star = prefix + (nb << lo) - 1u;            // every key below bin nb of this prefix range
                 ok = upto > 0 && nb < nbins;                    // (nb == nbins cannot happen while more than `head` keys are in range)
                 break;
@@ -748,7 +786,7 @@ __global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __res
             pos = lo - 1;
             __syncthreads();
         }
-        if (!ok) return;                                        // one score value shared by hundreds of candidates: general path
+        if (!ok) return false;                                       // one score value shared by hundreds of candidates: general path
     }
     uint32_t n_le = 0, n;
 #pragma unroll
@@ -758,15 +796,24 @@ __global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __res
     for (int c = 0; c < EN2_HR; ++c)
         if (kreg[c] <= key_star) { if (pos < (uint32_t)EN2_HEAD) tmpk[pos] = ((uint64_t)kreg[c] << 32) | freg[c]; ++pos; }
     if (tid < EN2_HEAD) rank[tid] = 0;
-    __syncthreads();
     n = n < (uint32_t)EN2_HEAD ? n : (uint32_t)EN2_HEAD;        // (n == head when cnt > head, else cnt)
-    {   // rank sort: thread (i, half) counts the keys of its half that precede key i; keys are distinct -> a permutation
-        const uint32_t i = tid & (EN2_HEAD - 1), half = tid >> 9;
+    if (tid >= (int)n && tid < EN2_HEAD) tmpk[tid] = ~0ull;     // sentinels: never "before" a key, so the count loop needs no bound
+    __syncthreads();
+    {   // rank sort: thread (i, part) counts the keys of its part that precede key i; keys are distinct -> a permutation.
+        // Trip count a multiple of 16 (sentinel padding) and unrolled: the broadcast LDS reads of a batch are in flight
+        // together (one read per iteration with a data-dependent bound cost a full LDS round trip each: 12.6 us of the
+        // kernel's 40); the loop is bound by its 64-bit compares, so all 1024 threads share the n x n comparisons.
+        const uint32_t sh = n <= 128u ? 7u : n <= 256u ? 8u : 9u;                 // keys padded to 128 / 256 / 512 ...
+        const uint32_t i = tid & ((1u << sh) - 1u), part = tid >> sh, parts = (uint32_t)EN_THREADS >> sh;   // ... 8 / 4 / 2 parts
+        const uint32_t plen = (((n + parts - 1u) / parts) + 15u) & ~15u;         // parts * plen <= EN2_HEAD
         if (i < n) {
             const uint64_t ki = tmpk[i];
+            const uint64_t* p = tmpk + part * plen;
             uint32_t r = 0;
-            const uint32_t j0 = half * (EN2_HEAD / 2), j1 = j0 + EN2_HEAD / 2 < n ? j0 + EN2_HEAD / 2 : n;
-            for (uint32_t j = j0; j < j1; ++j) r += tmpk[j] < ki ? 1u : 0u;
+            for (uint32_t j0 = 0; j0 < plen; j0 += 16) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r += p[j0 + j] < ki ? 1u : 0u;
+            }
             atomicAdd(&rank[i], r);
         }
     }
@@ -780,8 +827,12 @@ __global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __res
         scl[r] = (uint16_t)(flat % (uint32_t)nc);
     }
     __syncthreads();
+    if (tid < 128) (&Mcol[0][0])[tid] = 0;
+    __syncthreads();
     int nk = 0;
     for (uint32_t t0 = 0; t0 < n && nk < max_out; t0 += 64) {
+        uint64_t* mc = Mcol[(t0 >> 6) & 1];
+        if (wave == 1) Mcol[((t0 >> 6) & 1) ^ 1][lane] = 0;      // the next tile's masks (last read before the previous tile's closing barrier)
         const uint32_t j = t0 + lane;
         const bool valid = j < n;
         const float4 bj = valid ? sb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -793,32 +844,21 @@ __global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __res
             d |= __ballot(valid && (uint32_t)kcl[k] == cj && iou_f32(bk, box_area(bk), bj, aj) > iou_thr);
         }
         if (lane == 0) dead[wave] = d;
+        uint64_t col = 0;                                       // in-tile suppressors of candidate j among this wave's rows
         for (int i = wave; i < 64; i += 16) {
             const uint32_t ji = t0 + i;
-            uint64_t m = 0;
             if (ji < n) {
                 const float4 bi = sb[ji];
-                m = __ballot(valid && lane > i && (uint32_t)scl[ji] == cj && iou_f32(bi, box_area(bi), bj, aj) > iou_thr);
+                if (valid && lane > i && (uint32_t)scl[ji] == cj && iou_f32(bi, box_area(bi), bj, aj) > iou_thr) col |= 1ull << i;
             }
-            if (lane == 0) Mrow[i] = m;
         }
+        if (col) atomicOr((unsigned long long*)&mc[lane], (unsigned long long)col);
         __syncthreads();
         uint64_t alive = __ballot(valid);
 #pragma unroll
         for (int w = 0; w < 16; ++w) alive &= ~dead[w];
-        const uint64_t myrow = Mrow[lane];
-        const uint32_t rlo = (uint32_t)myrow, rhi = (uint32_t)(myrow >> 32);
-        uint64_t keptmask = 0;
-        int nk2 = nk;
-        while (alive && nk2 < max_out) {
-            const int i = __builtin_ctzll(alive);
-            keptmask |= 1ull << i;
-            ++nk2;
-            const uint64_t row = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)rlo, i);
-            alive &= ~row;
-            alive &= ~(1ull << i);
-        }
+        const uint64_t keptmask = tile_resolve(alive, mc[lane], max_out - nk);
+        const int nk2 = nk + __builtin_popcountll(keptmask);
         if (wave == 0 && ((keptmask >> lane) & 1ull)) {
             const int r = nk + __builtin_popcountll(keptmask & ((1ull << lane) - 1ull));
             kbox[r] = bj; kcl[r] = (uint16_t)cj; kkey[r] = keys[j];
@@ -826,7 +866,7 @@ __global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __res
         nk = nk2;
         __syncthreads();
     }
-    if (nk < max_out && cnt > n) return;                        // the head did not suffice: general path (done stays 0)
+    if (nk < max_out && cnt > n) return false;                       // the head did not suffice: general path (done stays 0)
     for (int i = tid; i < max_out; i += EN_THREADS) {
         const size_t o = (size_t)b * max_out + i;
         if (i < nk) {
@@ -840,7 +880,9 @@ __global__ __launch_bounds__(EN_THREADS) void en2_head_kernel(const float* __res
         }
     }
     if (tid == 0) { num_dets[b] = nk; ws.done[b] = 1u; }
+    return true;
 }
+
 
 // per-class greedy NMS over one image's candidate list.  TIER 0: classes with <= 1024 candidates (256 threads, 26 KB of LDS,
 // several workgroups per CU); TIER 1: up to 4096 (1024 threads).  Both are launched over the same (nc, B) grid and a
@@ -852,18 +894,18 @@ __device__ __forceinline__ void en2_one_class(unsigned char* smem, const float* 
     uint64_t* keys = (uint64_t*)smem;                          // CAP
     float4* sb = (float4*)(keys + CAP);                        // CAP   boxes in sorted order
     float4* kbox = sb + CAP;                                   // max_out kept boxes
-    uint64_t* Mrow = (uint64_t*)(kbox + max_out);              // 64 in-tile suppression rows
-    uint64_t* dead = Mrow + 64;                                // NW partial masks
+    uint64_t* Mcol = (uint64_t*)(kbox + max_out);              // 2 x 64 in-tile suppressor masks (double-buffered over tiles)
+    uint64_t* dead = Mcol + 128;                               // NW partial masks
     uint32_t* misc = (uint32_t*)(dead + NW);                   // [0] n_c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t n_c;
-    uint32_t n = ws.count[b];
-    n = n < (uint32_t)K ? n : (uint32_t)K;
+    uint32_t n = __atomic_load_n(&ws.count[b], __ATOMIC_RELAXED);     // (coherent loads: inside en2_front_kernel the list and
+    n = n < (uint32_t)K ? n : (uint32_t)K;                           //  the counts come from other workgroups of the same launch)
     const uint64_t* list = ws.cand + (size_t)b * ws.lcap;
     if (tid == 0) misc[0] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += THREADS) {
-        const uint64_t k = list[i];
+        const uint64_t k = __atomic_load_n(list + i, __ATOMIC_RELAXED);
         if ((uint32_t)k % (uint32_t)nc == (uint32_t)c) {
             const uint32_t pos = atomicAdd(&misc[0], 1u);
             if (pos < (uint32_t)CAP) keys[pos] = k;
@@ -879,8 +921,12 @@ __device__ __forceinline__ void en2_one_class(unsigned char* smem, const float* 
     __syncthreads();
 
     uint64_t* out = ws.kept + ((size_t)b * nc + c) * max_out;
+    if (tid < 128) Mcol[tid] = 0;
+    __syncthreads();
     int nk = 0;
     for (uint32_t t0 = 0; t0 < n_c && nk < max_out; t0 += 64) {
+        uint64_t* mc = Mcol + ((t0 >> 6) & 1) * 64;
+        if (wave == 1) Mcol[(((t0 >> 6) & 1) ^ 1) * 64 + lane] = 0;   // the next tile's masks (last read before the previous tile's closing barrier)
         const uint32_t j = t0 + lane;
         const bool valid = j < n_c;
         const float4 bj = valid ? sb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -892,34 +938,23 @@ __device__ __forceinline__ void en2_one_class(unsigned char* smem, const float* 
             d |= __ballot(valid && iou_f32(bk, box_area(bk), bj, aj) > iou_thr);
         }
         if (lane == 0) dead[wave] = d;
-        // (2) in-tile suppression rows: row i = which later members of the tile candidate i would suppress
+        // (2) in-tile suppression: which earlier members of the tile would suppress candidate j (this wave's share of the rows)
+        uint64_t col = 0;
         for (int i = wave; i < 64; i += NW) {
             const uint32_t ji = t0 + i;
-            uint64_t m = 0;
             if (ji < n_c) {                                     // uniform
                 const float4 bi = sb[ji];
-                m = __ballot(valid && lane > i && iou_f32(bi, box_area(bi), bj, aj) > iou_thr);
+                if (valid && lane > i && iou_f32(bi, box_area(bi), bj, aj) > iou_thr) col |= 1ull << i;
             }
-            if (lane == 0) Mrow[i] = m;
         }
+        if (col) atomicOr((unsigned long long*)&mc[lane], (unsigned long long)col);
         __syncthreads();
-        // (3) the sequential part, one 64-bit word: every wave resolves the tile redundantly (uniform control flow)
+        // (3) the sequential part: every wave resolves the tile redundantly (tile_resolve: parallel rounds)
         uint64_t alive = __ballot(valid);
 #pragma unroll
         for (int w = 0; w < NW; ++w) alive &= ~dead[w];
-        const uint64_t myrow = Mrow[lane];
-        const uint32_t rlo = (uint32_t)myrow, rhi = (uint32_t)(myrow >> 32);
-        uint64_t keptmask = 0;
-        int nk2 = nk;
-        while (alive && nk2 < max_out) {
-            const int i = __builtin_ctzll(alive);
-            keptmask |= 1ull << i;
-            ++nk2;
-            const uint64_t row = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)rlo, i);
-            alive &= ~row;
-            alive &= ~(1ull << i);
-        }
+        const uint64_t keptmask = tile_resolve(alive, mc[lane], max_out - nk);
+        const int nk2 = nk + __builtin_popcountll(keptmask);
         if (wave == 0 && ((keptmask >> lane) & 1ull)) {
             const int r = nk + __builtin_popcountll(keptmask & ((1ull << lane) - 1ull));
             kbox[r] = bj;
@@ -932,62 +967,34 @@ __device__ __forceinline__ void en2_one_class(unsigned char* smem, const float* 
     __syncthreads();
 }
 
-// TIER 0: one workgroup per (class, image), classes with 1..1024 candidates
-__global__ __launch_bounds__(256) void en2_class_small_kernel(const float* __restrict__ boxes, int A, int nc, float iou_thr,
-                                                              int max_out, int K, En2Ws ws) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int c = blockIdx.x, b = blockIdx.y;
-    if (ws.done[b]) return;
-    const uint32_t n_c = ws.ccount[(size_t)b * nc + c];
-    if (n_c == 0 || n_c > 1024u) return;                       // nkept was zeroed by the memset node of this call
-    en2_one_class<1024, 256>(smem, boxes, A, nc, c, b, iou_thr, max_out, K, ws);
-}
-
-// TIER 1: one workgroup per image walks the image's heavy classes (more than 1024 candidates: at most K / 1024 of them)
-__global__ __launch_bounds__(1024) void en2_class_large_kernel(const float* __restrict__ boxes, int A, int nc, float iou_thr,
-                                                               int max_out, int K, En2Ws ws) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t heavy[16];
-    __shared__ uint32_t n_heavy;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (ws.done[b]) return;
-    if (tid == 0) n_heavy = 0;
-    __syncthreads();
-    for (int c = tid; c < nc; c += 1024)
-        if (ws.ccount[(size_t)b * nc + c] > 1024u) { const uint32_t p = atomicAdd(&n_heavy, 1u); if (p < 16u) heavy[p] = (uint32_t)c; }
-    __syncthreads();
-    const int nh = (int)(n_heavy < 16u ? n_heavy : 16u);
-    for (int h = 0; h < nh; ++h) en2_one_class<EN_MAXK, 1024>(smem, boxes, A, nc, (int)heavy[h], b, iou_thr, max_out, K, ws);
-}
-
-__global__ __launch_bounds__(256) void en2_merge_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                        int A, int nc, int max_out, En2Ws ws, int32_t* __restrict__ num_dets,
-                                                        float* __restrict__ out_boxes, float* __restrict__ out_scores,
-                                                        int32_t* __restrict__ out_labels) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// final step, once per image: the first max_out of the union of the per-class kept lists (by score, flat index) = what the
+// sequential scan keeps first; `smem`: EN_MAXK keys.
+__device__ __forceinline__ void en2_merge_body(unsigned char* smem, const float* __restrict__ boxes, const float* __restrict__ scores,
+                                               int A, int nc, int max_out, const En2Ws& ws, int b, int32_t* __restrict__ num_dets,
+                                               float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                               int32_t* __restrict__ out_labels) {
     uint64_t* keys = (uint64_t*)smem;                          // EN_MAXK
     __shared__ uint32_t tot_sh;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (ws.done[b]) return;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     if (tid == 0) tot_sh = 0;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
-    for (int c = wave; c < nc; c += 4) {                       // a wave per class list (order is irrelevant: sorted below)
-        const uint32_t nkc = ws.nkept[(size_t)b * nc + c];
+    for (int c = wave; c < nc; c += nthr >> 6) {                       // a wave per class list (order is irrelevant: sorted below)
+        const uint32_t nkc = __atomic_load_n(&ws.nkept[(size_t)b * nc + c], __ATOMIC_RELAXED);
         if (!nkc) continue;
         uint32_t off = lane == 0 ? atomicAdd(&tot_sh, nkc) : 0u;
         off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
         const uint64_t* src = ws.kept + ((size_t)b * nc + c) * max_out;
-        for (uint32_t k = lane; k < nkc; k += 64) if (off + k < (uint32_t)EN_MAXK) keys[off + k] = src[k];
+        for (uint32_t k = lane; k < nkc; k += 64) if (off + k < (uint32_t)EN_MAXK) keys[off + k] = __atomic_load_n(src + k, __ATOMIC_RELAXED);
     }
     __syncthreads();
     const int n = (int)(tot_sh < (uint32_t)EN_MAXK ? tot_sh : (uint32_t)EN_MAXK);
     const int np = next_pow2(n, 64);
-    for (int i = n + tid; i < np; i += 256) keys[i] = ~0ull;
+    for (int i = n + tid; i < np; i += nthr) keys[i] = ~0ull;
     bitonic_sort_u64(keys, np);
     const int nout = n < max_out ? n : max_out;
     const float4* Bx = (const float4*)boxes + (size_t)b * A;
-    for (int i = tid; i < max_out; i += 256) {
+    for (int i = tid; i < max_out; i += nthr) {
         const size_t o = (size_t)b * max_out + i;
         if (i < nout) {
             const uint32_t flat = (uint32_t)keys[i];
@@ -1001,6 +1008,68 @@ __global__ __launch_bounds__(256) void en2_merge_kernel(const float* __restrict_
         }
     }
     if (tid == 0) num_dets[b] = nout;
+}
+
+// en2_front_kernel, one workgroup per image: head -> [exact top-K select] -> [the image's heavy classes].  One launch where there
+// were three (head, select, class_large): a dependent launch costs the stream ~4 us even when its workgroups exit at once, and
+// at batch 32 the whole NMS is 30-40 us.  Measured and rejected: (i) this workgroup streaming the image's scores itself instead
+// of the en2_filter_kernel grid (three latency-bound batches on one CU: 42 -> 52 us per call at batch 32, 60 -> 129 us at batch
+// 256); (ii) filter chunks and head in one launch with a "last workgroup of the image goes on" ticket, and the same for the
+// merge: the release / acquire fences the hand-over needs write back and invalidate the XCD's L2 (the chunks of an image run
+// on different XCDs): 70 us at batch 32, 540 us at batch 256.
+__global__ __launch_bounds__(EN_THREADS) void en2_front_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                               int A, int nc, float score_thr, float iou_thr, int max_out, int K,
+                                                               En2Ws ws, int32_t* __restrict__ num_dets,
+                                                               float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                               int32_t* __restrict__ out_labels) {
+    __shared__ SelLds L;
+    __shared__ uint32_t cc[EN2_CC_LDS];
+    __shared__ uint32_t heavy[16];
+    __shared__ uint32_t n_heavy;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];     // en2_one_class<EN_MAXK> (covers the head's kept boxes)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    uint32_t cnt;                                              // (loaded by the head)
+    if (en2_head_body(boxes, scores, A, nc, iou_thr, max_out, K, ws, b, cnt, L, dyn, num_dets, out_boxes, out_scores, out_labels))
+        return;
+    __syncthreads();
+    if (cnt > (uint32_t)K) {                                   // else the list already is the selected set
+        en2_select_body(scores, A, nc, score_thr, K, ws, b, L, cc);
+        __threadfence_block();                                 // the rewritten list / counts are read back below (coherent loads)
+        __syncthreads();
+    }
+    // heavy classes (more than 1024 selected candidates: at most K / 1024 of them), one after the other in this workgroup
+    if (tid == 0) n_heavy = 0;
+    __syncthreads();
+    for (int c = tid; c < nc; c += EN_THREADS)
+        if (__atomic_load_n(&ws.ccount[(size_t)b * nc + c], __ATOMIC_RELAXED) > 1024u) {
+            const uint32_t p = atomicAdd(&n_heavy, 1u);
+            if (p < 16u) heavy[p] = (uint32_t)c;
+        }
+    __syncthreads();
+    const int nh = (int)(n_heavy < 16u ? n_heavy : 16u);
+    for (int h = 0; h < nh; ++h) en2_one_class<EN_MAXK, 1024>(dyn, boxes, A, nc, (int)heavy[h], b, iou_thr, max_out, K, ws);
+}
+
+// en2_classes_kernel, grid (nc, B) x 256 threads, only for images the head could not finish: per-class greedy NMS of the classes
+// with 1..1024 selected candidates (26 KB of LDS, several workgroups per CU).
+__global__ __launch_bounds__(256) void en2_classes_kernel(const float* __restrict__ boxes, int A, int nc, float iou_thr,
+                                                          int max_out, int K, En2Ws ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int c = blockIdx.x, b = blockIdx.y;
+    if (ws.done[b]) return;
+    const uint32_t n_c = ws.ccount[(size_t)b * nc + c];
+    if (n_c == 0 || n_c > 1024u) return;                       // nkept was zeroed by the memset node of this call
+    en2_one_class<1024, 256>(smem, boxes, A, nc, c, b, iou_thr, max_out, K, ws);
+}
+
+__global__ __launch_bounds__(256) void en2_merge_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                        int A, int nc, int max_out, En2Ws ws, int32_t* __restrict__ num_dets,
+                                                        float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                        int32_t* __restrict__ out_labels) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    if (ws.done[b]) return;
+    en2_merge_body(smem, boxes, scores, A, nc, max_out, ws, b, num_dets, out_boxes, out_scores, out_labels);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1254,19 +1323,23 @@ extern "C" int yv_efficient_nms_ws(const float* boxes, const float* scores, int 
     const int total = A * nc;
     const int chunks = (total + EN2_FT * EN2_FPT - 1) / (EN2_FT * EN2_FPT);
     hipLaunchKernelGGL(en2_filter_kernel, dim3(chunks, B), dim3(EN2_FT), 0, st, scores, total, nc, score_threshold, pre_topk, w);
-    hipLaunchKernelGGL(en2_head_kernel, dim3(B), dim3(EN_THREADS), (size_t)max_out * (16 + 8 + 2) + 16, st, boxes, scores, A, nc,
-                       score_threshold, iou_threshold, max_out, pre_topk, w, num_dets, out_boxes, out_scores, out_labels);
-    hipLaunchKernelGGL(en2_select_kernel, dim3(B), dim3(EN_THREADS), 0, st, scores, A, nc, score_threshold, pre_topk, w);
-    auto lds_of = [&](int cap, int nw) { return (size_t)cap * (8 + 16) + (size_t)max_out * 16 + 64 * 8 + (size_t)nw * 8 + 16; };
-    const size_t lds0 = lds_of(1024, 4), lds1 = lds_of(EN_MAXK, 16);
-    if (hipFuncSetAttribute((const void*)en2_class_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) !=
-        hipSuccess)
-        return YV_ERR_LAUNCH;
-    if (lds0 > 65536 && hipFuncSetAttribute((const void*)en2_class_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds0) != hipSuccess)
-        return YV_ERR_LAUNCH;
-    hipLaunchKernelGGL(en2_class_small_kernel, dim3(nc, B), dim3(256), lds0, st, boxes, A, nc, iou_threshold, max_out, pre_topk, w);
-    hipLaunchKernelGGL(en2_class_large_kernel, dim3(B), dim3(1024), lds1, st, boxes, A, nc, iou_threshold, max_out, pre_topk, w);
+    auto lds_of = [&](int cap, int nw) { return (size_t)cap * (8 + 16) + (size_t)max_out * 16 + 128 * 8 + (size_t)nw * 8 + 16; };
+    const size_t head_dyn = (size_t)max_out * (16 + 8 + 2) + 16;
+    const size_t lds1 = lds_of(EN_MAXK, 16) > head_dyn ? lds_of(EN_MAXK, 16) : head_dyn, lds0 = lds_of(1024, 4);
+    static size_t attr_front = 0, attr_classes = 0;             // dynamic-LDS limits already granted (they only ever grow)
+    if (lds1 > attr_front) {
+        if (hipFuncSetAttribute((const void*)en2_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess)
+            return YV_ERR_LAUNCH;
+        attr_front = lds1;
+    }
+    if (lds0 > 32768 && lds0 > attr_classes) {
+        if (hipFuncSetAttribute((const void*)en2_classes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0) != hipSuccess)
+            return YV_ERR_LAUNCH;
+        attr_classes = lds0;
+    }
+    hipLaunchKernelGGL(en2_front_kernel, dim3(B), dim3(EN_THREADS), lds1, st, boxes, scores, A, nc, score_threshold, iou_threshold,
+                       max_out, pre_topk, w, num_dets, out_boxes, out_scores, out_labels);
+    hipLaunchKernelGGL(en2_classes_kernel, dim3(nc, B), dim3(256), lds0, st, boxes, A, nc, iou_threshold, max_out, pre_topk, w);
     hipLaunchKernelGGL(en2_merge_kernel, dim3(B), dim3(256), (size_t)EN_MAXK * 8, st, boxes, scores, A, nc, max_out, w, num_dets,
                        out_boxes, out_scores, out_labels);
     return yv_launch_status();
@@ -1300,3 +1373,4 @@ extern "C" int yv_compact_crops(const int32_t* det_count, const int32_t* crop_re
                        crop_ok, B, slots, cap, crop_list, crop_total);
     return yv_launch_status();
 }
+
