@@ -81,6 +81,7 @@ struct GemmArgs {
     const float* resf;           // f32 residual source (null: read-modify-write `out`)
     uint16_t* aux;               // bf16 side buffer: SAVE_PRE target / GELU_BWD pre-activation
     int ldaux;
+    int cin_shift;               // conv: log2(c0 + c1) when that is a power of two, else -1
     int splitk;                  // conv only: K range split over `splitk` workgroups per tile (partials in `partial`)
     float* partial;              // (splitk, M, N) f32
     int staged;                  // coalesced LDS-staged epilogue usable (alignment / width checked on the host)
@@ -92,7 +93,12 @@ struct GemmArgs {
     long long mx_rows;
 };
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) through the hardware reciprocal (1 ulp) instead of an IEEE division: the division's scale / fixup sequence was
+// ~12 of the ~20 VALU instructions per output value of every detector convolution, in kernels that are VALU-issue-bound.
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// 256 bytes of zeros: where a staged chunk is padding (outside the image, past K, past the last row) the conv / linear gather
+// reads THIS instead of branching around the load or masking the data afterwards
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
 // erf-form GELU through x * sigmoid(x * (p0 + p1 x^2 + p2 x^4)), coefficients fitted (minimax, |x| <= 8) against
 // 0.5 x (1 + erf(x / sqrt 2)): max abs error 2.5e-5 - below half a bf16 step of the output everywhere the output exceeds
 // 0.01 in magnitude.  x^2 is clamped at 64 (beyond |x| = 8 the result is x or 0 to f32 precision; the quartic would turn over).
@@ -378,12 +384,19 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
     if (m0 >= M) return;
 
     // ---- per-thread staging coordinates -------------------------------------------------
+    // Everything that does not change along K is worked out once per tile: per activation row the byte offset of the output
+    // pixel's centre in each source and the 3 x 3 taps that fall inside the image (9 bits), per weight row its byte offset.  A K
+    // step then costs one tap decode per thread (its 8-channel chunk is fixed) and an add + a bit test per 16-byte load - the
+    // first version redid the pixel arithmetic (64-bit multiplies, a division) for every load: 45 VALU instructions per load,
+    // 330 per wave and step against 32 MFMAs (SQ_INSTS_VALU / SQ_INSTS_VMEM_RD over the detector's launches).
     const int ch = tid & 7;                        // chunk (8 elements) within the 64-wide K step
     const int r_in = tid >> 3;                     // 0..31
     // activation rows handled by this thread: r_in + 32*p
     int a_valid[A_CH];
-    long long a_base[A_CH];                        // linear: row offset; conv: unused
-    int a_b[A_CH], a_oy[A_CH], a_ox[A_CH];
+    long long a_base[A_CH];                        // linear: row offset
+    uint32_t a_off0[A_CH], a_off1[A_CH], a_taps[A_CH];      // conv (32-bit byte offsets: conv_impl bounds the tensors)
+    const int pad = g.ksize >> 1;
+    const int Cin = g.c0 + g.c1;
 #pragma unroll
     for (int p = 0; p < A_CH; ++p) {
         const int m = m0 + r_in + 32 * p;
@@ -394,48 +407,78 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
             const int hw = g.Hout * g.Wout;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / g.Wout;
-            a_b[p] = b; a_oy[p] = oy * g.stride; a_ox[p] = (rem - oy * g.Wout) * g.stride;
+            const int cy = oy * g.stride, cx = (rem - oy * g.Wout) * g.stride;
+            a_off0[p] = (uint32_t)((((long long)b * (g.Hin >> g.up0) + (cy >> g.up0)) * (g.Win >> g.up0) + (cx >> g.up0)) * g.lda0 * 2);
+            // (kept as the DIFFERENCE to a_off0: a runtime choice between two register arrays would put both in scratch)
+            a_off1[p] = g.c1 ? (uint32_t)((((long long)b * (g.Hin >> g.up1) + (cy >> g.up1)) * (g.Win >> g.up1) + (cx >> g.up1)) * g.lda1 * 2) - a_off0[p] : 0u;
+            uint32_t taps = 0;
+            if (a_valid[p]) {
+                if (g.ksize == 3) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+                        taps |= (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) ? (1u << t) : 0u;
+                    }
+                } else {
+                    taps = 1u;
+                }
+            }
+            a_taps[p] = taps;
         }
     }
-    const int pad = g.ksize >> 1;
-    const int Cin = g.c0 + g.c1;
+    uint32_t w_off[W_CH];
+    bool w_ok[W_CH];
+#pragma unroll
+    for (int p = 0; p < W_CH; ++p) {
+        const int rr = r_in + 32 * p;
+        w_ok[p] = rr < BN && (n0 + rr) < g.N;
+        w_off[p] = (uint32_t)(((long long)(n0 + rr) * g.K + ch * 8) * 2);
+    }
 
+    // Loads are UNCONDITIONAL: a chunk that is padding / past K / past the matrix edge reads g_zero_page instead.  Written as
+    // "if (valid) r = load" hipcc branches around every load and waits vmcnt(0) before the next one - 8 dependent memory round
+    // trips per K step instead of 8 loads in flight (s_waitcnt vmcnt(0) in front of every global_load of the first version).
+    // (the empty asm makes the chosen address an opaque VALUE: without it hipcc turns the ternary back into two branches)
     uint4 ra[A_CH], rw[W_CH];
+    const unsigned char* zp = (const unsigned char*)g_zero_page;
+    typedef const __attribute__((address_space(1))) u32x4* g16_t;   // (global, not generic: a flat load would also count in lgkmcnt)
+    auto ld16 = [&](bool ok, const unsigned char* ptr) __attribute__((always_inline)) {
+        g16_t q = (g16_t)(ok ? ptr : zp);
+        asm volatile("" : "+v"(q));
+        const u32x4 v = *q;
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    };
     auto load_tile = [&](int kt) {
         const int k = kt * BK + ch * 8;
         const bool k_ok = k < g.K;
         if (MODE == 0) {
 #pragma unroll
-            for (int p = 0; p < A_CH; ++p) {
-                ra[p] = make_uint4(0, 0, 0, 0);
-                if (k_ok && a_valid[p]) ra[p] = *(const uint4*)(g.a0 + a_base[p] + k);
-            }
+            for (int p = 0; p < A_CH; ++p)
+                ra[p] = ld16(k_ok && a_valid[p], (const unsigned char*)(g.a0 + a_base[p] + k));
         } else {
             int tap = 0, cin = k;
-            if (g.ksize == 3) { tap = k / Cin; cin = k - tap * Cin; }
-            const int ky = g.ksize == 3 ? tap / 3 : 0;
-            const int kx = g.ksize == 3 ? tap - ky * 3 : 0;
-            const bool s1 = cin >= g.c0;
-            const uint16_t* src = s1 ? g.a1 : g.a0;
-            const int ld = s1 ? g.lda1 : g.lda0;
-            const int up = s1 ? g.up1 : g.up0;
-            const int cc = s1 ? cin - g.c0 : cin;
+            int delta = 0;                                     // byte offset of this step's (tap, channel) from the centre pixel
+            const unsigned char* src = (const unsigned char*)g.a0;
+            uint32_t m1 = 0;                                   // all ones when this lane's chunk comes from the second source
+            if (g.ksize == 3) {                                // (3 x 3 convolutions read one source at its own resolution)
+                tap = g.cin_shift >= 0 ? (k >> g.cin_shift) : k / Cin;
+                cin = k - tap * Cin;
+                const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), kx = tap - ky * 3;
+                delta = (((ky - pad) * g.Win + (kx - pad)) * g.lda0 + cin) * 2;
+            } else {
+                const bool s1 = g.c1 > 0 && cin >= g.c0;
+                delta = (s1 ? cin - g.c0 : cin) * 2;
+                if (s1) { src = (const unsigned char*)g.a1; m1 = 0xFFFFFFFFu; }
+            }
 #pragma unroll
             for (int p = 0; p < A_CH; ++p) {
-                ra[p] = make_uint4(0, 0, 0, 0);
-                const int iy = a_oy[p] + ky - pad, ix = a_ox[p] + kx - pad;
-                if (k_ok && a_valid[p] && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) {
-                    const int sy = iy >> up, sx = ix >> up, sh = g.Hin >> up, sw = g.Win >> up;
-                    ra[p] = *(const uint4*)(src + ((long long)(a_b[p] * sh + sy) * sw + sx) * ld + cc);
-                }
+                const bool ok = k_ok && ((a_taps[p] >> tap) & 1u);
+                ra[p] = ld16(ok, src + (uint32_t)(a_off0[p] + (a_off1[p] & m1) + (uint32_t)delta));
             }
         }
 #pragma unroll
-        for (int p = 0; p < W_CH; ++p) {
-            const int rr = r_in + 32 * p;
-            rw[p] = make_uint4(0, 0, 0, 0);
-            if (rr < BN && k_ok && (n0 + rr) < g.N) rw[p] = *(const uint4*)(g.w + (long long)(n0 + rr) * g.K + k);
-        }
+        for (int p = 0; p < W_CH; ++p)
+            rw[p] = ld16(w_ok[p] && k_ok, (const unsigned char*)g.w + (uint32_t)(w_off[p] + (uint32_t)kt * (BK * 2)));
     };
     auto store_tile = [&](int buf) {
         unsigned char* A = smem + buf * (A_BYTES + W_BYTES);
@@ -464,11 +507,14 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
 
     const int nk_all = (g.K + BK - 1) / BK;
     const int kt0 = (int)((long long)nk_all * slice / S), nk = (int)((long long)nk_all * (slice + 1) / S);
+    // ONE LDS buffer: the next step's operands wait in registers while this step's MFMAs read the tile, and go to LDS between
+    // two barriers.  The launches are latency-bound (a gather per step, ~0.2 us of MFMAs), so what counts is how many workgroups
+    // a CU holds, and half the LDS (32 KB at 128 x 128) lets the register budget decide: 3 per CU instead of 2.
     load_tile(kt0);
     store_tile(0);
     __syncthreads();
     for (int kt = kt0; kt < nk; ++kt) {
-        const int cur = (kt - kt0) & 1;
+        constexpr int cur = 0;
         if (kt + 1 < nk) load_tile(kt + 1);
         const unsigned char* A = smem + cur * (A_BYTES + W_BYTES);
         const unsigned char* W = A + A_BYTES;
@@ -492,7 +538,8 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
                 for (int j = 0; j < MF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();                                       // every wave has read the tile
+        if (kt + 1 < nk) store_tile(0);
         __syncthreads();
     }
 
@@ -1623,7 +1670,8 @@ template <int MODE, int BM, int BN, int WM, int WN>
 int launch(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    size_t lds = (size_t)(BM + BN) * 128;
+    if (lds < (size_t)THREADS / 64 * (BM / WM) * 128) lds = (size_t)THREADS / 64 * (BM / WM) * 128;   // the staged epilogue's slabs
     auto kern = igemm_kernel<MODE, BM, BN, WM, WN>;
     if (lds > 65536) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1867,7 +1915,15 @@ static int conv_impl(const yv_view* in0, const yv_view* in1, int B, int Hout, in
     if ((flags & YV_EPI_RES_BF16) && (!res || (res_ld & 3))) return YV_ERR_ARG;
     if (flags & (YV_EPI_GELU | YV_EPI_POSEMB | YV_EPI_RES_F32)) return YV_ERR_ARG;
     if ((long long)B * Hout * Wout > 0x7fffffffLL) return YV_ERR_LIMIT;
+    if (ksize == 3 && in0->up) return YV_ERR_ARG;                 // the fused 2x upsample is a property of 1 x 1 (concat) inputs
+    {   // the kernel addresses activations and weights with 32-bit byte offsets
+        const long long px = (long long)B * Hout * stride * Wout * stride;
+        if (px * in0->ld * 2 >= 0x100000000LL || (c1 && px * in1->ld * 2 >= 0x100000000LL) ||
+            (long long)Cout * ksize * ksize * Cin * 2 >= 0x100000000LL)
+            return YV_ERR_LIMIT;
+    }
     GemmArgs g = {};
+    g.cin_shift = (Cin & (Cin - 1)) == 0 ? __builtin_ctz((unsigned)Cin) : -1;
     g.a0 = (const uint16_t*)in0->ptr; g.lda0 = in0->ld; g.c0 = in0->c; g.up0 = in0->up;
     if (c1) { g.a1 = (const uint16_t*)in1->ptr; g.lda1 = in1->ld; g.c1 = c1; g.up1 = in1->up; }
     g.Hin = Hout * stride; g.Win = Wout * stride;
