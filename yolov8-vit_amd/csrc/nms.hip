@@ -666,50 +666,45 @@ __device__ __forceinline__ uint64_t tile_resolve(uint64_t alive, uint64_t col, i
 
 constexpr int EN2_HEAD = 512;                // capacity of the head: images with this many candidates or fewer are taken whole
 constexpr int EN2_WIN = 320;                 // otherwise a prefix of EN2_WIN/2 .. EN2_WIN members (rank sort cost grows with its square)
-constexpr int EN2_HR = 16;                  // candidate keys per thread held by en2_head_kernel (16 x 1024 = the list capacity)
+constexpr int EN2_HR = 16;                  // candidate keys per thread, images with up to 16 K candidates ...
+constexpr int EN2_HRW = ES_CACHE;           // ... and up to 44 K (keys only: the flat index of a selected key is re-read from the list)
+struct HeadLds {                            // (one instance in the kernel: the two instantiations of the head share it)
+    uint64_t keys[EN2_HEAD];                // unordered, then sorted
+    uint64_t tmpk[EN2_HEAD];
+    uint32_t rank[EN2_HEAD];
+    float4 sb[EN2_HEAD];
+    uint16_t scl[EN2_HEAD];
+    uint64_t Mcol[2][64];                   // in-tile suppressor masks, double-buffered over tiles
+    uint64_t dead[16];
+};
+template <int NR>
 __device__ __forceinline__ bool en2_head_body(const float* __restrict__ boxes, const float* __restrict__ scores, int A, int nc,
-                                              float iou_thr, int max_out, int K, const En2Ws& ws, int b, uint32_t& cnt,
-                                              SelLds& L, unsigned char* dyn, int32_t* __restrict__ num_dets,
+                                              float iou_thr, int max_out, int K, const En2Ws& ws, int b, uint32_t cnt,
+                                              SelLds& L, HeadLds& H, unsigned char* dyn, int32_t* __restrict__ num_dets,
                                               float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                               int32_t* __restrict__ out_labels) {
-    __shared__ uint64_t keys[EN2_HEAD];                        // unordered, then sorted
-    __shared__ uint64_t tmpk[EN2_HEAD];
-    __shared__ uint32_t rank[EN2_HEAD];
-    __shared__ float4 sb[EN2_HEAD];
-    __shared__ uint16_t scl[EN2_HEAD];
-    __shared__ uint64_t Mcol[2][64];                           // in-tile suppressor masks, double-buffered over tiles
-    __shared__ uint64_t dead[16];
+    uint64_t (&keys)[EN2_HEAD] = H.keys;
+    uint64_t (&tmpk)[EN2_HEAD] = H.tmpk;
+    uint32_t (&rank)[EN2_HEAD] = H.rank;
+    float4 (&sb)[EN2_HEAD] = H.sb;
+    uint16_t (&scl)[EN2_HEAD] = H.scl;
+    uint64_t (&Mcol)[2][64] = H.Mcol;
+    uint64_t (&dead)[16] = H.dead;
     float4* kbox = (float4*)dyn;                               // kept boxes (max_out float4), keys, classes
     uint64_t* kkey = (uint64_t*)(kbox + max_out);
     uint16_t* kcl = (uint16_t*)(kkey + max_out);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int total = A * nc;
     const float* S = scores + (size_t)b * total;
-    // the image's candidates were compacted into its list by en2_filter_kernel (the launch before): up to 16 per thread.
-    // The first half of the registers is fetched before the count is known (the workspace is readable up to lcap whatever it
-    // holds): one global round trip instead of two on the kernel's critical path.
+    // the image's candidates were compacted into its list by en2_filter_kernel (the launch before): up to NR per thread
     const uint64_t* list = ws.cand + (size_t)b * ws.lcap;
-    uint64_t raw[EN2_HR];
+    uint32_t kreg[NR];
 #pragma unroll
-    for (int c = 0; c < EN2_HR / 2; ++c) {
+    for (int c = 0; c < NR; ++c) {
         const uint32_t i = (uint32_t)(c * EN_THREADS + tid);
-        raw[c] = i < (uint32_t)ws.lcap ? list[i] : ~0ull;
+        kreg[c] = i < cnt ? ((const uint32_t*)list)[2 * i + 1] : 0xFFFFFFFFu;       // (the key is the high word of the entry)
     }
     for (int i = tid; i < 16 * 256; i += EN_THREADS) (&L.hist[0][0])[i] = 0;     // (for the first histogram pass, under the loads)
-    cnt = ws.count[b];
-    if (cnt > (uint32_t)ws.lcap || cnt > (uint32_t)(EN2_HR * EN_THREADS)) return false;      // general path
-#pragma unroll
-    for (int c = EN2_HR / 2; c < EN2_HR; ++c) {
-        const uint32_t i = (uint32_t)(c * EN_THREADS + tid);
-        raw[c] = i < cnt ? list[i] : ~0ull;
-    }
-    uint32_t kreg[EN2_HR], freg[EN2_HR];
-#pragma unroll
-    for (int c = 0; c < EN2_HR; ++c) {
-        const bool in = (uint32_t)(c * EN_THREADS + tid) < cnt;
-        kreg[c] = in ? (uint32_t)(raw[c] >> 32) : 0xFFFFFFFFu;
-        freg[c] = in ? (uint32_t)raw[c] : 0u;
-    }
     const uint32_t head = (uint32_t)(K < EN2_HEAD ? K : EN2_HEAD);
     const uint32_t win = head < (uint32_t)EN2_WIN ? head : (uint32_t)EN2_WIN;     // prefix size aimed at when a cut is needed
     uint32_t key_star = 0xFFFFFFFEu;                            // take every candidate
@@ -719,7 +714,7 @@ __device__ __forceinline__ bool en2_head_body(const float* __restrict__ boxes, c
         // boundary bin straddles the window; a digit boundary never splits equal keys, so ties need no care here
         uint32_t ka = 0xFFFFFFFFu, ko = 0u;
 #pragma unroll
-        for (int c = 0; c < EN2_HR; ++c)
+        for (int c = 0; c < NR; ++c)
             if (kreg[c] != 0xFFFFFFFFu) { ka &= kreg[c]; ko |= kreg[c]; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { ka &= __shfl_xor(ka, o, 64); ko |= __shfl_xor(ko, o, 64); }
@@ -744,7 +739,7 @@ __device__ __forceinline__ bool en2_head_body(const float* __restrict__ boxes, c
             }
             first = false;
 #pragma unroll
-            for (int c = 0; c < EN2_HR; ++c) {
+            for (int c = 0; c < NR; ++c) {
                 const uint32_t k = kreg[c];
                 if (k != 0xFFFFFFFFu && (k & hi_mask) == prefix) atomicAdd(&L.hist[wave][(k >> lo) & (nbins - 1u)], 1u);
             }
@@ -790,11 +785,11 @@ __device__ __forceinline__ bool en2_head_body(const float* __restrict__ boxes, c
     }
     uint32_t n_le = 0, n;
 #pragma unroll
-    for (int c = 0; c < EN2_HR; ++c) n_le += (kreg[c] <= key_star) ? 1u : 0u;        // the sentinel ~0 is above every cut
+    for (int c = 0; c < NR; ++c) n_le += (kreg[c] <= key_star) ? 1u : 0u;        // the sentinel ~0 is above every cut
     uint32_t pos = block_excl_scan(n_le, L, n);
 #pragma unroll
-    for (int c = 0; c < EN2_HR; ++c)
-        if (kreg[c] <= key_star) { if (pos < (uint32_t)EN2_HEAD) tmpk[pos] = ((uint64_t)kreg[c] << 32) | freg[c]; ++pos; }
+    for (int c = 0; c < NR; ++c)
+        if (kreg[c] <= key_star) { if (pos < (uint32_t)EN2_HEAD) tmpk[pos] = list[c * EN_THREADS + tid]; ++pos; }
     if (tid < EN2_HEAD) rank[tid] = 0;
     n = n < (uint32_t)EN2_HEAD ? n : (uint32_t)EN2_HEAD;        // (n == head when cnt > head, else cnt)
     if (tid >= (int)n && tid < EN2_HEAD) tmpk[tid] = ~0ull;     // sentinels: never "before" a key, so the count loop needs no bound
@@ -1023,14 +1018,21 @@ __global__ __launch_bounds__(EN_THREADS) void en2_front_kernel(const float* __re
                                                                float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                                int32_t* __restrict__ out_labels) {
     __shared__ SelLds L;
+    __shared__ HeadLds H;
     __shared__ uint32_t cc[EN2_CC_LDS];
     __shared__ uint32_t heavy[16];
     __shared__ uint32_t n_heavy;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];     // en2_one_class<EN_MAXK> (covers the head's kept boxes)
     const int b = blockIdx.x, tid = threadIdx.x;
-    uint32_t cnt;                                              // (loaded by the head)
-    if (en2_head_body(boxes, scores, A, nc, iou_thr, max_out, K, ws, b, cnt, L, dyn, num_dets, out_boxes, out_scores, out_labels))
-        return;
+    const uint32_t cnt = ws.count[b];
+    bool done = false;                                         // (cnt beyond the list capacity: general path)
+    if (cnt <= (uint32_t)(EN2_HR * EN_THREADS))
+        done = en2_head_body<EN2_HR>(boxes, scores, A, nc, iou_thr, max_out, K, ws, b, cnt, L, H, dyn, num_dets, out_boxes,
+                                     out_scores, out_labels);
+    else if (cnt <= (uint32_t)ws.lcap)
+        done = en2_head_body<EN2_HRW>(boxes, scores, A, nc, iou_thr, max_out, K, ws, b, cnt, L, H, dyn, num_dets, out_boxes,
+                                      out_scores, out_labels);
+    if (done) return;
     __syncthreads();
     if (cnt > (uint32_t)K) {                                   // else the list already is the selected set
         en2_select_body(scores, A, nc, score_thr, K, ws, b, L, cc);
@@ -1277,7 +1279,7 @@ extern "C" int yv_efficient_nms(const float* boxes, const float* scores, int B, 
 // scores), never less than pre_topk, never more than there are scores
 static int en2_lcap(int A, int nc, int K) {
     const long long total = (long long)A * nc;
-    long long c = total < 16384 ? total : 16384;
+    long long c = total < (long long)EN2_HRW * EN_THREADS ? total : (long long)EN2_HRW * EN_THREADS;
     if (c < K) c = K;
     return (int)((c + 63) & ~63LL);
 }
