@@ -52,6 +52,33 @@ __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restr
     __syncthreads();
     const uint8_t* src = images + (size_t)img * img_stride;
     const int groups = S >> 3;                       // 8 output pixels per item
+    if (LAYOUT == 2) {
+        // patch-major bf16 (the classifier's operand): one item = 8 consecutive output pixels of a row, ALL THREE channels - the
+        // 8 column-table reads and the row / patch arithmetic are shared by the channels, and the 24 source bytes are 8 runs
+        // of 3 adjacent bytes (the first version gave each channel its own item: three times the LDS reads and index math for
+        // the same bytes)
+        const int items = rows_per_block * groups;
+        const int gp = S / P;                        // patches per side
+        for (int it = threadIdx.x; it < items; it += CR_THREADS) {
+            const int g = it % groups, yl = it / groups;
+            const int y = row0 + yl, x = g * 8;
+            const uint8_t* line = src + (size_t)ty_sh[yl] * (size_t)W * 3;
+            float v[3][8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint8_t* px = line + tx[x + q];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c][q] = norm_u8(px[c], rcp);
+            }
+            const size_t row = (size_t)r * gp * gp + (size_t)(y / P) * gp + (x / P);
+            uint16_t* o = (uint16_t*)out + row * (size_t)(3 * P * P) + (y % P) * P + (x % P);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                *(uint4*)(o + (size_t)c * P * P) = make_uint4(pack_bf16x2(v[c][0], v[c][1]), pack_bf16x2(v[c][2], v[c][3]),
+                                                              pack_bf16x2(v[c][4], v[c][5]), pack_bf16x2(v[c][6], v[c][7]));
+        }
+        return;
+    }
     const int items = rows_per_block * 3 * groups;
     for (int it = threadIdx.x; it < items; it += CR_THREADS) {
         int g = it % groups;
@@ -68,18 +95,9 @@ __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restr
             ((float4*)o)[0] = make_float4(v[0], v[1], v[2], v[3]);
             ((float4*)o)[1] = make_float4(v[4], v[5], v[6], v[7]);
         } else {
-            uint4 pk = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                  pack_bf16x2(v[6], v[7]));
-            uint16_t* o;
-            if (LAYOUT == 1) {
-                o = (uint16_t*)out + (((size_t)r * 3 + c) * S + y) * S + g * 8;
-            } else {
-                const int gp = S / P;                // patches per side
-                const int x = g * 8;
-                const size_t row = (size_t)r * gp * gp + (size_t)(y / P) * gp + (x / P);
-                o = (uint16_t*)out + row * (size_t)(3 * P * P) + (size_t)c * P * P + (y % P) * P + (x % P);
-            }
-            *(uint4*)o = pk;
+            uint16_t* o = (uint16_t*)out + (((size_t)r * 3 + c) * S + y) * S + g * 8;
+            *(uint4*)o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                    pack_bf16x2(v[6], v[7]));
         }
     }
 }
