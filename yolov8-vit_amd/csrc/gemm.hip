@@ -82,6 +82,7 @@ struct GemmArgs {
     uint16_t* aux;               // bf16 side buffer: SAVE_PRE target / GELU_BWD pre-activation
     int ldaux;
     int cin_shift;               // conv: log2(c0 + c1) when that is a power of two, else -1
+    int tap_uniform;             // conv: (c0 + c1) % 64 == 0, a K step lies inside one tap
     int splitk;                  // conv only: K range split over `splitk` workgroups per tile (partials in `partial`)
     float* partial;              // (splitk, M, N) f32
     int staged;                  // coalesced LDS-staged epilogue usable (alignment / width checked on the host)
@@ -356,7 +357,7 @@ __device__ __forceinline__ void finish_tile(const GemmArgs& g, f32x4 (&acc)[NF][
     epilogue<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane & 15, lane >> 4);
 }
 
-template <int MODE /*0 linear, 1 conv*/, int BM, int BN, int WM, int WN>
+template <int MODE /*0 linear, 1 conv*/, int BM, int BN, int WM, int WN, bool TWO = false /*conv with two concatenated sources*/>
 __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
     constexpr int MF = BM / WM / 16;               // activation fragments per wave
     constexpr int NF = BN / WN / 16;               // weight fragments per wave
@@ -408,9 +409,10 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / g.Wout;
             const int cy = oy * g.stride, cx = (rem - oy * g.Wout) * g.stride;
-            a_off0[p] = (uint32_t)((((long long)b * (g.Hin >> g.up0) + (cy >> g.up0)) * (g.Win >> g.up0) + (cx >> g.up0)) * g.lda0 * 2);
-            // (kept as the DIFFERENCE to a_off0: a runtime choice between two register arrays would put both in scratch)
-            a_off1[p] = g.c1 ? (uint32_t)((((long long)b * (g.Hin >> g.up1) + (cy >> g.up1)) * (g.Win >> g.up1) + (cx >> g.up1)) * g.lda1 * 2) - a_off0[p] : 0u;
+            // (both include this lane's 8-channel chunk; a_off1 is kept as the DIFFERENCE to a_off0: a runtime choice between two
+            //  register arrays would put both in scratch)
+            a_off0[p] = (uint32_t)((((long long)b * (g.Hin >> g.up0) + (cy >> g.up0)) * (g.Win >> g.up0) + (cx >> g.up0)) * g.lda0 * 2) + ch * 16;
+            a_off1[p] = g.c1 ? (uint32_t)((((long long)b * (g.Hin >> g.up1) + (cy >> g.up1)) * (g.Win >> g.up1) + (cx >> g.up1)) * g.lda1 * 2) + ch * 16 - a_off0[p] : 0u;
             uint32_t taps = 0;
             if (a_valid[p]) {
                 if (g.ksize == 3) {
@@ -435,52 +437,84 @@ __global__ __launch_bounds__(THREADS) void igemm_kernel(GemmArgs g) {
         w_off[p] = (uint32_t)(((long long)(n0 + rr) * g.K + ch * 8) * 2);
     }
 
-    // Loads are UNCONDITIONAL: a chunk that is padding / past K / past the matrix edge reads g_zero_page instead.  Written as
-    // "if (valid) r = load" hipcc branches around every load and waits vmcnt(0) before the next one - 8 dependent memory round
-    // trips per K step instead of 8 loads in flight (s_waitcnt vmcnt(0) in front of every global_load of the first version).
-    // (the empty asm makes the chosen address an opaque VALUE: without it hipcc turns the ternary back into two branches)
+    // Loads are UNCONDITIONAL.  Written as "if (valid) r = load" hipcc branches around every load and waits vmcnt(0) before the
+    // next one - 8 dependent memory round trips per K step instead of 8 loads in flight (s_waitcnt vmcnt(0) in front of every
+    // global_load of the first version).  Conv: buffer loads, a chunk that is padding / past K / past the last row gets an
+    // out-of-range offset and reads zeros through the descriptor's range check; whatever is the same for the whole workgroup in a
+    // K step (the tap's displacement, the channel base, the weight column) travels in the instruction's SCALAR offset, so a load
+    // costs a bit test and a select.  The scalar offset is unsigned, hence the descriptor's base one row + one pixel before the
+    // tensor.  Linear: a 64-bit address chosen between the operand and g_zero_page.
     uint4 ra[A_CH], rw[W_CH];
     const unsigned char* zp = (const unsigned char*)g_zero_page;
     typedef const __attribute__((address_space(1))) u32x4* g16_t;   // (global, not generic: a flat load would also count in lgkmcnt)
     auto ld16 = [&](bool ok, const unsigned char* ptr) __attribute__((always_inline)) {
         g16_t q = (g16_t)(ok ? ptr : zp);
-        asm volatile("" : "+v"(q));
+        asm volatile("" : "+v"(q));                         // an opaque VALUE: hipcc would turn the choice back into two branches
         const u32x4 v = *q;
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + ch * 8;
+    constexpr uint32_t OOB = 0x80000000u;
+    const uint32_t bias0 = MODE == 1 && g.ksize == 3 ? (uint32_t)((g.Win + 1) * g.lda0 * 2) : 0u;
+    // (copies first: a ternary between two FIELDS of the by-value kernel argument selects between their addresses; and the
+    //  descriptors are built inside the lambda - captured by reference they are objects hipcc cannot keep out of memory, and the
+    //  whole closure, kernel argument included, lands in scratch)
+    const unsigned char* const a0p = (const unsigned char*)g.a0 - bias0;
+    const unsigned char* const a1p = (const unsigned char*)g.a1;
+    const unsigned char* const wp = (const unsigned char*)g.w;
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+        const int kb = kt * BK;                                // (uniform)
+        const int k = kb + ch * 8;
         const bool k_ok = k < g.K;
         if (MODE == 0) {
 #pragma unroll
             for (int p = 0; p < A_CH; ++p)
                 ra[p] = ld16(k_ok && a_valid[p], (const unsigned char*)(g.a0 + a_base[p] + k));
+#pragma unroll
+            for (int p = 0; p < W_CH; ++p)
+                rw[p] = ld16(w_ok[p] && k_ok, (const unsigned char*)g.w + (uint32_t)(w_off[p] + (uint32_t)kb * 2));
+        } else if constexpr (TWO) {
+            // two concatenated sources (1 x 1 convolutions after a Concat): the source is a per-lane property in general, so this
+            // instance keeps 64-bit addresses (a choice between two descriptors - as objects, as base pointers, or as two
+            // branches that both load into ra[] - makes hipcc keep the arrays and the kernel argument in scratch)
+            const bool s1 = k_ok && k >= g.c0;
+            const unsigned char* src = (const unsigned char*)(s1 ? a1p : a0p);
+            const uint32_t m1 = s1 ? 0xFFFFFFFFu : 0u;
+            const uint32_t d = (uint32_t)((s1 ? k - g.c0 : k) * 2) - ch * 16;
+#pragma unroll
+            for (int p = 0; p < A_CH; ++p)
+                ra[p] = ld16(k_ok && (a_taps[p] & 1u), src + (uint32_t)(a_off0[p] + (a_off1[p] & m1) + d));
+#pragma unroll
+            for (int p = 0; p < W_CH; ++p)
+                rw[p] = ld16(w_ok[p] && k_ok, wp + (uint32_t)(w_off[p] + (uint32_t)kb * 2));
         } else {
-            int tap = 0, cin = k;
-            int delta = 0;                                     // byte offset of this step's (tap, channel) from the centre pixel
-            const unsigned char* src = (const unsigned char*)g.a0;
-            uint32_t m1 = 0;                                   // all ones when this lane's chunk comes from the second source
-            if (g.ksize == 3) {                                // (3 x 3 convolutions read one source at its own resolution)
-                tap = g.cin_shift >= 0 ? (k >> g.cin_shift) : k / Cin;
-                cin = k - tap * Cin;
+            int tap = 0;                                       // (per lane only when a K step spans several taps: Cin < 64)
+            uint32_t soff = bias0, dl = 0;
+            if (g.ksize == 3) {
+                const int kk = g.tap_uniform ? kb : k;
+                tap = g.cin_shift >= 0 ? (kk >> g.cin_shift) : kk / Cin;
+                const int cin = kk - tap * Cin;
                 const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), kx = tap - ky * 3;
-                delta = (((ky - pad) * g.Win + (kx - pad)) * g.lda0 + cin) * 2;
+                const uint32_t d = (uint32_t)((((ky - pad) * g.Win + (kx - pad)) * g.lda0 + cin) * 2);
+                if (g.tap_uniform) soff += (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                else dl = d - ch * 16;
             } else {
-                const bool s1 = g.c1 > 0 && cin >= g.c0;
-                delta = (s1 ? cin - g.c0 : cin) * 2;
-                if (s1) { src = (const unsigned char*)g.a1; m1 = 0xFFFFFFFFu; }
+                soff = (uint32_t)(kb * 2);
             }
+            const auto rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a0p, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
             for (int p = 0; p < A_CH; ++p) {
-                const bool ok = k_ok && ((a_taps[p] >> tap) & 1u);
-                ra[p] = ld16(ok, src + (uint32_t)(a_off0[p] + (a_off1[p] & m1) + (uint32_t)delta));
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs0, (k_ok && ((a_taps[p] >> tap) & 1u)) ? a_off0[p] + dl : OOB, soff, 0);
+                ra[p] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+            const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int p = 0; p < W_CH; ++p) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, (w_ok[p] && k_ok) ? w_off[p] : OOB, (uint32_t)kb * 2, 0);
+                rw[p] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
-#pragma unroll
-        for (int p = 0; p < W_CH; ++p)
-            rw[p] = ld16(w_ok[p] && k_ok, (const unsigned char*)g.w + (uint32_t)(w_off[p] + (uint32_t)kt * (BK * 2)));
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
         unsigned char* A = smem + buf * (A_BYTES + W_BYTES);
         unsigned char* W = A + A_BYTES;
 #pragma unroll
@@ -1679,7 +1713,8 @@ int launch(GemmArgs& g, hipStream_t st) {
     g.tiles_n = (g.N + BN - 1) / BN;
     size_t lds = (size_t)(BM + BN) * 128;
     if (lds < (size_t)THREADS / 64 * (BM / WM) * 128) lds = (size_t)THREADS / 64 * (BM / WM) * 128;   // the staged epilogue's slabs
-    auto kern = igemm_kernel<MODE, BM, BN, WM, WN>;
+    void (*kern)(GemmArgs) = igemm_kernel<MODE, BM, BN, WM, WN, false>;
+    if constexpr (MODE == 1) { if (g.c1 > 0) kern = igemm_kernel<MODE, BM, BN, WM, WN, true>; }
     if (lds > 65536) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return YV_ERR_LAUNCH;
@@ -1925,12 +1960,13 @@ static int conv_impl(const yv_view* in0, const yv_view* in1, int B, int Hout, in
     if (ksize == 3 && in0->up) return YV_ERR_ARG;                 // the fused 2x upsample is a property of 1 x 1 (concat) inputs
     {   // the kernel addresses activations and weights with 32-bit byte offsets
         const long long px = (long long)B * Hout * stride * Wout * stride;
-        if (px * in0->ld * 2 >= 0x100000000LL || (c1 && px * in1->ld * 2 >= 0x100000000LL) ||
-            (long long)Cout * ksize * ksize * Cin * 2 >= 0x100000000LL)
+        if (px * in0->ld * 2 >= 0x7fffffffLL || (c1 && px * in1->ld * 2 >= 0x7fffffffLL) ||
+            (long long)Cout * ksize * ksize * Cin * 2 >= 0x7fffffffLL)
             return YV_ERR_LIMIT;
     }
     GemmArgs g = {};
     g.cin_shift = (Cin & (Cin - 1)) == 0 ? __builtin_ctz((unsigned)Cin) : -1;
+    g.tap_uniform = (Cin % 64) == 0;
     g.a0 = (const uint16_t*)in0->ptr; g.lda0 = in0->ld; g.c0 = in0->c; g.up0 = in0->up;
     if (c1) { g.a1 = (const uint16_t*)in1->ptr; g.lda1 = in1->ld; g.c1 = c1; g.up1 = in1->up; }
     g.Hin = Hout * stride; g.Win = Wout * stride;
