@@ -220,7 +220,7 @@ def bench_postproc(args, dev):
                        "mean_num_dets": float(num.float().mean())},
             "roofline": {"bound": "hbm", "achieved": nms_bytes / res["nms"] * 1e-3, "peak": peak, "unit": "GB/s",
                          "frac": nms_bytes / res["nms"] * 1e-3 / peak, "traffic": None,
-                         "kernel": "en2_filter + en2_front + en2_classes + en2_merge (EfficientNMS, per call)",
+                         "kernel": "en2_filter + en2_front + en2_tail (EfficientNMS, per call)",
                          "us_per_call": res["nms"], "alg_bytes_per_call": nms_bytes},
             "crop_roofline": {"bound": "hbm", "achieved": crop_bytes / res["crop"] * 1e-3, "peak": peak, "unit": "GB/s",
                               "frac": crop_bytes / res["crop"] * 1e-3 / peak, "kernel": "crop_kernel<2>",
