@@ -123,6 +123,31 @@ def test_efficient_nms_ties_on_cut_and_empty(yv, single_kernel):
     assert int(got[0][0, 0]) == 0 and float(got[1].abs().sum()) == 0 and float(got[2].abs().sum()) == 0
 
 
+def test_efficient_nms_suppression_chains(yv):
+    """Worst case for the parallel-round tile resolution (nms.hip tile_resolve): chains in which candidate i overlaps only
+    candidates i-1 and i+1, so whether i is kept depends on ALL earlier members (kept, dead, kept, ...: as many rounds as the
+    tile has members), chains that straddle 64-wide tile boundaries, plus a single class with every box identical (one kept,
+    hundreds suppressed across many tiles)."""
+    g = torch.Generator().manual_seed(31)
+    B, A, nc = 3, 400, 2
+    x0 = torch.arange(A, dtype=torch.float32) * 7.0                   # width 20, step 7: IoU(i, i+1) = 13/27 = 0.48, IoU(i, i+2) = 6/34 = 0.18
+    boxes = torch.stack([x0, torch.zeros(A), x0 + 20.0, torch.full((A,), 20.0)], -1)[None].repeat(B, 1, 1).contiguous()
+    boxes[2] = torch.tensor([100.0, 100.0, 180.0, 190.0])            # image 2: identical boxes
+    scores = torch.zeros(B, A, nc)
+    scores[0, :, 0] = torch.linspace(0.95, 0.30, A)                   # image 0: one chain in rank order
+    perm = torch.randperm(A, generator=g)
+    scores[1, :, 0] = torch.linspace(0.95, 0.30, A)[perm]             # image 1: the same boxes, ranks shuffled along the chain
+    scores[1, :, 1] = torch.linspace(0.90, 0.26, A)
+    scores[2, :, 1] = torch.linspace(0.99, 0.31, A)
+    for iou in (0.45, 0.15, 0.65):
+        exp = ob.efficient_nms(boxes, scores, 0.25, iou, 100, 4096)
+        for sk in (False, True):
+            got = yv.efficient_nms(boxes.to(DEV), scores.to(DEV), 0.25, iou, 100, 4096, single_kernel=sk)
+            for e, g_ in zip(exp, got):
+                assert torch.equal(e, g_.cpu()), (iou, sk)
+    assert int(exp[0][2, 0]) == 1 and int(exp[0][0, 0]) == 100
+
+
 def test_efficient_nms_clustered_boxes_and_small_limits(yv):
     """Heavy suppression (clusters of near-identical boxes: many tiles are walked before max_out boxes are kept, kept lists
     of several classes interleave in the merge), small max_out / pre_topk, threshold variations; the two device forms must

@@ -20,7 +20,8 @@ g = [r for r in rows if pat in r["Name"]]
 calls = sum(int(r["Calls"]) for r in g); tot = sum(float(r["TotalDurationNs"]) for r in g)
 summary = {"kernel": pat, "calls": calls, "avg_us": tot / calls / 1e3,
            "share_of_gpu_time": tot / sum(float(r["TotalDurationNs"]) for r in rows),
-           "instances": {r["Name"].split("(")[0][-40:]: {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3} for r in g}}
+           "instances": {r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", ""):
+                         {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3} for r in g}}
 if len(argv) >= 4:
     def pmc(d, name):
         f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
