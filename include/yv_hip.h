@@ -105,8 +105,9 @@ int yv_efficient_nms(const float* boxes, const float* scores, int B, int A, int 
                      float* out_scores, int32_t* out_labels, void* stream);
 
 /* Same contract (tech.md:41-47, test.ipynb:20-24), multi-workgroup form: the candidate filter streams the scores at
- * HBM rate over (A*nc / 4096, B) workgroups, per-class greedy NMS runs as (nc, B) workgroups (sort + 64-wide tiles whose
- * suppression masks are built by ballots), a per-image merge takes the first max_out of the union - bit-identical to
+ * HBM rate over (A*nc / 4096, B) workgroups; one workgroup per image then resolves a prefix of the ranking (all the
+ * sequential scan looks at before the max_out-th kept box: radix cut, rank sort, 64-wide tiles), and only images it
+ * cannot finish go through the exact top-pre_topk select, per-class greedy NMS and a merge - bit-identical to
  * yv_efficient_nms.  `ws`: caller-owned scratch of yv_efficient_nms_ws_bytes() bytes, 256-byte aligned, private to the
  * call while it is in flight.  This is the form the pipeline uses; the single-kernel form above needs no scratch. */
 size_t yv_efficient_nms_ws_bytes(int B, int A, int nc, int max_out, int pre_topk);
@@ -214,7 +215,10 @@ typedef struct yv_view {
  * in0 (+ optional in1 = channel concat, 1x1 only) are (B,Hin,Win,*) views;
  * weight (Cout, k*k*Cin) bf16 with K order (ky,kx,cin); bias (Cout) f32;
  * out = (B,Hout,Wout,*) view with pixel stride out_ld (bf16, or f32 with YV_EPI_OUT_F32);
- * res = optional bf16 residual view (same pixel grid as out). */
+ * res = optional bf16 residual view (same pixel grid as out).
+ * Limits: the fused 2x upsample (yv_view.up) is a property of 1x1 inputs (YV_ERR_ARG with ksize 3); the kernel
+ * addresses each source and the weights with 32-bit byte offsets: B*Hin*Win*ld*2 and Cout*k*k*Cin*2 must stay
+ * below 2 GB (YV_ERR_LIMIT). */
 int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
               const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res, int res_ld,
               int flags, void* stream);
