@@ -1960,7 +1960,8 @@ static int conv_impl(const yv_view* in0, const yv_view* in1, int B, int Hout, in
     if (ksize == 3 && in0->up) return YV_ERR_ARG;                 // the fused 2x upsample is a property of 1 x 1 (concat) inputs
     {   // the kernel addresses activations and weights with 32-bit byte offsets
         const long long px = (long long)B * Hout * stride * Wout * stride;
-        if (px * in0->ld * 2 >= 0x7fffffffLL || (c1 && px * in1->ld * 2 >= 0x7fffffffLL) ||
+        // (+ one row and one pixel: the 3 x 3 descriptor starts that far before the tensor, see igemm_kernel)
+        if ((px + Wout * stride + 1) * in0->ld * 2 >= 0x7fffffffLL || (c1 && px * in1->ld * 2 >= 0x7fffffffLL) ||
             (long long)Cout * ksize * ksize * Cin * 2 >= 0x7fffffffLL)
             return YV_ERR_LIMIT;
     }
