@@ -148,6 +148,53 @@ def test_efficient_nms_suppression_chains(yv):
     assert int(exp[0][2, 0]) == 1 and int(exp[0][0, 0]) == 100
 
 
+def test_efficient_nms_properties_at_bench_batch(yv):
+    """Size-independent properties at the post-processing bench's full size (256 images x 8400 anchors x 5 classes, SURVEY 8(d)
+    score / box distributions): the oracle checks the first 6 images bit for bit; for all 256 the output must be sorted by
+    score, hold no pair of same-class boxes above the IoU threshold, carry the input's own scores, be zero padded - and be a
+    fixed point: feeding the kept boxes back (one-hot class scores) keeps every one of them in the same order."""
+    B, A, nc, thr, iou_thr, K = 256, 8400, 5, 0.25, 0.65, 100
+    g = torch.Generator().manual_seed(4321)
+    ctr = torch.rand(B, A, 2, generator=g) * 640
+    wh = torch.rand(B, A, 2, generator=g) * 240 + 16
+    boxes = torch.cat([(ctr - wh / 2).clamp(0, 640), (ctr + wh / 2).clamp(0, 640)], -1).contiguous()
+    scores = torch.distributions.Beta(0.5, 4.0).sample((B, A, nc)).float()
+    bd, sd = boxes.to(DEV), scores.to(DEV)
+    num, kb, ks, kl = yv.efficient_nms(bd, sd, thr, iou_thr, K)
+    exp = ob.efficient_nms(boxes[:6], scores[:6], thr, iou_thr, K)
+    for e, g_ in zip(exp, (num[:6], kb[:6], ks[:6], kl[:6])):
+        assert torch.equal(e, g_.cpu())
+    n = num[:, 0].long()
+    slot = torch.arange(K, device=DEV)[None]
+    live = slot < n[:, None]
+    assert bool((n <= K).all()) and int(n.min()) > 0
+    assert float(ks[~live].abs().sum()) == 0 and float(kb[~live].abs().sum()) == 0 and int(kl[~live].abs().sum()) == 0
+    d = ks[:, 1:] - ks[:, :-1]
+    assert bool((d[live[:, 1:]] <= 0).all())                          # sorted by score
+    assert bool((ks[live] > thr).all())
+    # every kept (box, score, label) is one of the image's candidates: its score is the anchor's score for that class
+    same_box = (kb[:, :, None, :] == bd[:, None, :, :]).all(-1)        # (B, K, A) - boolean, chunked to bound memory
+    for b0 in range(0, B, 32):
+        sb = same_box[b0:b0 + 32]
+        cand = torch.gather(sd[b0:b0 + 32].permute(0, 2, 1), 1, kl[b0:b0 + 32].long()[:, :, None].expand(-1, -1, A))   # (b, K, A)
+        hit = (sb & (cand == ks[b0:b0 + 32][:, :, None])).any(-1)
+        assert bool(hit[live[b0:b0 + 32]].all())
+    # no same-class pair above the threshold
+    x1 = torch.maximum(kb[:, :, None, 0], kb[:, None, :, 0]); y1 = torch.maximum(kb[:, :, None, 1], kb[:, None, :, 1])
+    x2 = torch.minimum(kb[:, :, None, 2], kb[:, None, :, 2]); y2 = torch.minimum(kb[:, :, None, 3], kb[:, None, :, 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    area = (kb[..., 2] - kb[..., 0]) * (kb[..., 3] - kb[..., 1])
+    iou = inter / (area[:, :, None] + area[:, None, :] - inter).clamp(min=1e-9)
+    pair = live[:, :, None] & live[:, None, :] & (kl[:, :, None] == kl[:, None, :]) & ~torch.eye(K, dtype=torch.bool, device=DEV)[None]
+    assert float(iou[pair].max()) <= iou_thr + 1e-6
+    # fixed point
+    s2 = torch.zeros(B, K, nc, device=DEV)
+    s2.scatter_(2, kl.long()[:, :, None], ks[:, :, None])
+    s2[~live] = 0
+    num2, kb2, ks2, kl2 = yv.efficient_nms(kb.contiguous(), s2, thr, iou_thr, K)
+    assert torch.equal(num2, num) and torch.equal(kb2, kb) and torch.equal(ks2, ks) and torch.equal(kl2, kl)
+
+
 def test_efficient_nms_clustered_boxes_and_small_limits(yv):
     """Heavy suppression (clusters of near-identical boxes: many tiles are walked before max_out boxes are kept, kept lists
     of several classes interleave in the merge), small max_out / pre_topk, threshold variations; the two device forms must
