@@ -334,6 +334,35 @@ def test_crop_resize_norm_bit_exact(yv):
     assert torch.equal(part[:2], f32[:2]) and float(part[2:].abs().sum()) == 0
 
 
+def test_crop_gather_at_bench_batch(yv):
+    """The crop gather at the post-processing bench's full size (256 images of 640 x 640, 1024 crops, patch-major bf16): 24
+    crops sampled across the batch bit for bit against the oracle; for every crop the three layouts must hold the same
+    values (the patch-major image un-patchified equals the planar bf16 image = RNE of the planar f32 image), and every value
+    lies in [-1, 1] on the 256-level grid (x - 127.5) / 127.5."""
+    B, S, R, P = 256, 640, 1024, 16
+    g = torch.Generator().manual_seed(77)
+    imgs = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
+    img_idx = torch.arange(R) % B
+    x0 = torch.randint(0, S - 8, (R,), generator=g); y0 = torch.randint(0, S - 8, (R,), generator=g)
+    w = torch.randint(1, 400, (R,), generator=g); h = torch.randint(1, 400, (R,), generator=g)
+    x1 = torch.minimum(x0 + w, torch.tensor(S)); y1 = torch.minimum(y0 + h, torch.tensor(S))
+    rects = torch.stack([img_idx, x0, y0, x1, y1, torch.zeros(R, dtype=torch.long)], 1).to(torch.int32)
+    cl = rects.to(DEV); tot = torch.tensor([R], dtype=torch.int32, device=DEV)
+    dimg = imgs.to(DEV)
+    pm = yv.crop_resize_norm(dimg, cl, tot, R, 224, P, layout=2)                    # (R * 196, 768) bf16
+    b16 = yv.crop_resize_norm(dimg, cl, tot, R, 224, P, layout=1)                   # (R, 3, 224, 224) bf16
+    f32 = yv.crop_resize_norm(dimg, cl, tot, R, 224, P, layout=0)                   # (R, 3, 224, 224) f32
+    assert torch.equal(f32.to(torch.bfloat16), b16)
+    unp = pm.view(R, 14, 14, 3, P, P).permute(0, 3, 1, 4, 2, 5).reshape(R, 3, 224, 224)
+    assert torch.equal(unp, b16)
+    lvl = f32 * 127.5 + 127.5
+    assert float(f32.abs().max()) <= 1.0 and float((lvl - lvl.round()).abs().max()) < 1e-3
+    for r in torch.randperm(R, generator=g)[:24].tolist():
+        rc = rects[r].tolist()
+        exp = ob.crop_resize_normalize(imgs[rc[0]].numpy(), rc[1:5])
+        assert np.array_equal(f32[r].cpu().numpy(), exp), r
+
+
 # ------------------------------------------------------------------ decode
 def test_detect_decode_vs_oracle(yv):
     B, nc, size = 2, 5, 640
