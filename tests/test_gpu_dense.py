@@ -328,15 +328,23 @@ def test_sppf_pool(yv):
     assert torch.equal(d[..., :c].cpu(), x)
 
 
-def test_stem_conv(yv):
-    g = torch.Generator().manual_seed(8)
-    B, H = 2, 64
-    img = torch.randint(0, 256, (B, H, H, 3), generator=g, dtype=torch.uint8)
-    w = torch.randn(16, 3, 3, 3, generator=g) * 0.3; b = torch.randn(16, generator=g) * 0.1
+@pytest.mark.parametrize("B,H,W,cout,ld", [(2, 64, 64, 16, 16), (2, 48, 256, 16, 16), (1, 130, 128, 32, 40), (3, 32, 384, 48, 48),
+                                           (1, 640, 640, 16, 16)])
+def test_stem_conv(yv, B, H, W, cout, ld):
+    """Both forms of the stem: scalar (any even size) and the matrix-pipe form taken when W % 128 == 0 (integer pixels against
+    w / 255 in two bf16 halves): same tolerance, borders (top row / left column padding) included; channels past cout untouched."""
+    g = torch.Generator().manual_seed(8 + W + cout)
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    img[:, 0] = 255; img[:, :, 0] = 254                              # loud borders: a wrong padding rule shows
+    w = torch.randn(cout, 3, 3, 3, generator=g) * 0.3; b = torch.randn(cout, generator=g) * 0.1
     ref = F.silu(F.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, w, b, stride=2, padding=1))
-    out = torch.zeros(B, H // 2, H // 2, 16, dtype=torch.bfloat16, device=DEV)
-    yv.stem_conv(img.to(DEV), w.permute(2, 3, 1, 0).reshape(27, 16).contiguous().to(DEV), b.to(DEV), out)
-    assert rel_l2(out.permute(0, 3, 1, 2).float().cpu(), ref) < 3e-3
+    out = torch.full((B, H // 2, W // 2, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    yv.stem_conv(img.to(DEV), w.permute(2, 3, 1, 0).reshape(27, cout).contiguous().to(DEV), b.to(DEV), out)
+    got = out[..., :cout].permute(0, 3, 1, 2).float().cpu()
+    assert rel_l2(got, ref) < 3e-3
+    err = (got - ref).abs()
+    assert bool((err <= 2e-3 + ref.abs() * 2.0 ** -7).all()), float(err.max())
+    assert bool((out[..., cout:] == 7.0).all())
 
 
 def test_gemm_8phase_race_screen(yv):

@@ -52,6 +52,111 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ i
     }
 }
 
+// The same stem as an implicit GEMM on the matrix pipes (used when a row of the output is a whole number of 64-pixel
+// chunks, e.g. 640 x 640 inputs): pixel values 0..255 are exact in bf16, so the product runs on INTEGER activations against
+// w / 255 split into a bf16 high and low half (two MFMAs per 16 pixels x 16 channels; the sum carries 16 weight bits, the
+// accumulation is f32) - against 432 scalar FMAs per output pixel on the VALU, which made stem_kernel the slowest launch of the
+// detector (100 us per 32 images for 144 MB of traffic).  K = 27 -> 32 slots, ordered so that a lane's 8 slots are 8
+// CONSECUTIVE bytes of one input row: lane group g < 3 holds bytes 0..7 of the 9-byte run (3 pixels x 3 channels) of kernel
+// row g, group 3 holds byte 8 of the three rows and five zeros.  One wave = 64 consecutive output pixels of one row.
+template <int COUT>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restrict__ img, int H, int W,
+                                                        const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                        uint16_t* __restrict__ out, int out_ld, int chunks) {
+    constexpr int NFR = COUT / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 3 * 512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int Ho = H >> 1, Wo = W >> 1, cpr = Wo >> 6;
+    bf16x8 wh[NFR], wl[NFR];
+    float4 bv[NFR];
+#pragma unroll
+    for (int i = 0; i < NFR; ++i) {
+        uint32_t ph[4], pl[4];
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+            float hi[2], lo[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int q = q2 * 2 + e;
+                const int k = fq < 3 ? fq * 9 + q : (q < 3 ? q * 9 + 8 : -1);
+                const float w = k >= 0 ? wgt[k * COUT + i * 16 + fr] * (1.0f / 255.0f) : 0.f;
+                hi[e] = bf16_to_f32((uint16_t)(pack_bf16x2(w, 0.f) & 0xffff));
+                lo[e] = w - hi[e];
+            }
+            ph[q2] = pack_bf16x2(hi[0], hi[1]);
+            pl[q2] = pack_bf16x2(lo[0], lo[1]);
+        }
+        const u32x4 vh = {ph[0], ph[1], ph[2], ph[3]}, vl = {pl[0], pl[1], pl[2], pl[3]};
+        wh[i] = __builtin_bit_cast(bf16x8, vh);
+        wl[i] = __builtin_bit_cast(bf16x8, vl);
+        bv[i] = *(const float4*)(bias + i * 16 + fq * 4);
+    }
+    // grid-stride over the chunks: the weight fragments above cost every wave a dependent load round trip, so a wave takes
+    // several chunks (one chunk per wave: 80 us per 32 images; the grid below: see yv_stem_conv)
+    for (int chunk = blockIdx.x * 4 + wave; chunk < chunks; chunk += gridDim.x * 4) {      // (uniform per wave)
+    const int row = chunk / cpr, c64 = chunk - row * cpr;    // row = b * Ho + oy
+    const int b = row / Ho, oy = row - b * Ho;
+    // The chunk's input - three rows of 129 pixels, 387 bytes each - is staged in a wave-private LDS window with ONE 8-byte
+    // buffer load per lane and row (lane-contiguous 512 bytes; bytes before the row start / above the image are out of range
+    // and read 0 = the zero padding), then picked byte by byte from LDS: as per-lane global byte loads the same 32 accesses per
+    // chunk took 80-100 us per 32 images, whatever the arithmetic around them (the texture path handles a byte gather at
+    // about a lane per clock).
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (size_t)b * H * W * 3), 0, H * W * 3, 0x00020000);
+    const int rowb = W * 3;
+    constexpr uint32_t OOB = 0x80000000u;
+    const int x0 = 6 * (c64 * 64) - 3;                        // first byte of the chunk's run in a row (-3 at the left border)
+    const int xa = x0 & ~7;                                   // window start, 8-byte aligned (floor also for -3 -> -8)
+    unsigned char* win = stage + wave * (3 * 512);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        const int xo = xa + lane * 8;                         // this lane's 8 bytes of the row (may start before / end after it)
+        // bytes of one row only: a window that ran past the row end would read the next row's first pixels (never used:
+        // the run ends at 6 ox + 5 <= 3 W - 1), before its start it must read zeros
+        // (window, row start and row end are all multiples of 8 bytes - W % 128 == 0 - so no 8-byte group straddles an edge)
+        const uint32_t o = (iy >= 0 && xo >= 0 && xo + 8 <= rowb) ? (uint32_t)(iy * rowb + xo) : OOB;
+        const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rs, o, 0, 0);
+        *(u32x2*)(win + ky * 512 + lane * 8) = d;             // wave-private window: LDS executes one wave's accesses in order
+    }
+    // LDS byte addresses of this lane's 8 slots relative to the pixel's run start (6 ox - 3 - xa)
+    int loff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int ky = fq < 3 ? fq : (q < 3 ? q : 0), t = fq < 3 ? q : 8;
+        loff[q] = ky * 512 + t - xa;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ox = c64 * 64 + g * 16 + fr;
+        const int xb = 6 * ox - 3;
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t byte = (fq < 3 || q < 3) ? (uint32_t)win[loff[q] + xb] : 0u;
+            v[q] = __float_as_uint((float)byte);
+        }
+        uint32_t pk[4];
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2)                        // integers <= 255 are exact in bf16: the top halves of their f32 forms
+            pk[q2] = __builtin_amdgcn_perm(v[2 * q2 + 1], v[2 * q2], 0x07060302u);
+        const u32x4 pa = {pk[0], pk[1], pk[2], pk[3]};
+        const bf16x8 fa = __builtin_bit_cast(bf16x8, pa);
+        uint16_t* o = out + ((size_t)row * Wo + ox) * out_ld + fq * 4;
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], fa, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], fa, acc, 0, 0, 0);
+            float r[4] = {acc[0] + bv[i].x, acc[1] + bv[i].y, acc[2] + bv[i].z, acc[3] + bv[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = r[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-r[e]));      // SiLU
+            *(uint2*)(o + i * 16) = make_uint2(pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]));
+        }
+    }
+    }
+}
+
 __device__ __forceinline__ void max8(float* m, uint4 v) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -112,6 +217,15 @@ extern "C" int yv_stem_conv(const uint8_t* images, int B, int H, int W, const fl
     const dim3 grid((unsigned)((npix + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     uint16_t* o = (uint16_t*)out;
+    if ((W % 128) == 0 && npix < 0x7fffffffLL && (long long)H * W * 3 < 0x7fffffffLL && ((uintptr_t)images & 7) == 0) {   // matrix-pipe form
+        const int chunks = (int)(npix / 64);
+        const int blocks = (chunks + 3) / 4;
+        const dim3 g4((unsigned)(blocks < 2048 ? blocks : 2048));          // 8 waves per SIMD in one pass, ~6 chunks per wave at 32 x 640 x 640
+        if (Cout == 16) hipLaunchKernelGGL(stem_mfma_kernel<16>, g4, block, 0, st, images, H, W, weight, bias, o, out_ld, chunks);
+        else if (Cout == 32) hipLaunchKernelGGL(stem_mfma_kernel<32>, g4, block, 0, st, images, H, W, weight, bias, o, out_ld, chunks);
+        else hipLaunchKernelGGL(stem_mfma_kernel<48>, g4, block, 0, st, images, H, W, weight, bias, o, out_ld, chunks);
+        return yv_launch_status();
+    }
     if (Cout == 16) hipLaunchKernelGGL(stem_kernel<16>, grid, block, 0, st, images, H, W, weight, bias, o, out_ld, npix);
     else if (Cout == 32) hipLaunchKernelGGL(stem_kernel<32>, grid, block, 0, st, images, H, W, weight, bias, o, out_ld, npix);
     else hipLaunchKernelGGL(stem_kernel<48>, grid, block, 0, st, images, H, W, weight, bias, o, out_ld, npix);
