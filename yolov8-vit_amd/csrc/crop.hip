@@ -18,6 +18,8 @@ namespace {
 
 constexpr int CR_THREADS = 256;
 constexpr int CR_MAX_S = 512;
+constexpr int CR_ROWS = 16;                  // source rows staged per block (= output rows per block)
+constexpr int CR_ROWB = 2048;                // bytes per staged row segment: crops up to 677 pixels wide, wider ones gather from global
 
 __device__ __forceinline__ int nearest_src(int d, int dst, int src) {
     double fx = __ddiv_rn((double)dst, (double)src);
@@ -37,6 +39,8 @@ __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restr
                                                           int rows_per_block, float rcp, void* __restrict__ out, int n_images) {
     __shared__ int tx[CR_MAX_S];
     __shared__ int ty_sh[64];
+    __shared__ int rshift[CR_ROWS];
+    __shared__ __attribute__((aligned(16))) unsigned char rowbuf[CR_ROWS][CR_ROWB + 8];   // (+8: the rows of a column sit in different banks)
     const int r = blockIdx.y;
     if (crop_total && r >= crop_total[0]) return;
     const int32_t* rec = crop_list + (size_t)r * 6;
@@ -51,6 +55,24 @@ __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restr
     for (int d = threadIdx.x; d < rows_per_block; d += CR_THREADS) ty_sh[d] = y0 + nearest_src(row0 + d, S, ch);
     __syncthreads();
     const uint8_t* src = images + (size_t)img * img_stride;
+    // Source rows through LDS.  A per-lane BYTE gather from global memory costs the texture path about a lane per clock whatever
+    // the cache does (measured on the detector's stem: 32 such loads per 64 pixels = 80-100 us per 32 images, 44 us once
+    // staged), and this kernel did 24 of them per 8 output pixels.  The block's rows_per_block source-row segments
+    // [3 x0, 3 x1) are copied with 8-byte loads of ALIGNED words (the word holding a valid byte lies in that byte's page,
+    // so the up to 7 bytes read around a segment can never fault), then gathered byte by byte from LDS.
+    const bool staged = rows_per_block <= CR_ROWS && cw * 3 + 16 <= CR_ROWB;
+    if (staged) {
+        const int words = (cw * 3 + 7 + 7) >> 3;                 // 8-byte words that cover a segment at any alignment
+        for (int it = threadIdx.x; it < rows_per_block * words; it += CR_THREADS) {
+            const int yl = it / words, u = it - yl * words;
+            const uintptr_t first = (uintptr_t)(src + (size_t)ty_sh[yl] * (size_t)W * 3 + (size_t)x0 * 3);
+            const int lead = (int)(first & 7);
+            if (u == 0) rshift[yl] = lead - x0 * 3;              // LDS byte of source byte b of the row = rshift + b
+            if (u * 8 < lead + cw * 3)                           // only words that hold a byte of the segment
+                *(uint2*)(rowbuf[yl] + u * 8) = *(const uint2*)((first & ~(uintptr_t)7) + (size_t)u * 8);
+        }
+        __syncthreads();
+    }
     const int groups = S >> 3;                       // 8 output pixels per item
     if (LAYOUT == 2) {
         // patch-major bf16 (the classifier's operand): one item = 8 consecutive output pixels of a row, ALL THREE channels - the
@@ -59,24 +81,34 @@ __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restr
         // the same bytes)
         const int items = rows_per_block * groups;
         const int gp = S / P;                        // patches per side
-        for (int it = threadIdx.x; it < items; it += CR_THREADS) {
-            const int g = it % groups, yl = it / groups;
-            const int y = row0 + yl, x = g * 8;
-            const uint8_t* line = src + (size_t)ty_sh[yl] * (size_t)W * 3;
-            float v[3][8];
+        auto run = [&](auto line_of) __attribute__((always_inline)) {
+            for (int it = threadIdx.x; it < items; it += CR_THREADS) {
+                // one patch row per block (P = 16 = rows_per_block): consecutive lanes take the two 8-pixel halves of consecutive
+                // rows of ONE patch, whose (channel, 16 x 16) block is 512 contiguous bytes of the operand - a wave's store is
+                // two full blocks instead of 32-byte pieces of 28 of them
+                const bool by_patch = P == 16 && rows_per_block == 16;
+                const int g = by_patch ? ((it >> 5) << 1) | (it & 1) : it % groups;
+                const int yl = by_patch ? (it >> 1) & 15 : it / groups;
+                const int y = row0 + yl, x = g * 8;
+                const auto line = line_of(yl);
+                float v[3][8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint8_t* px = line + tx[x + q];
+                for (int q = 0; q < 8; ++q) {
+                    const auto px = line + tx[x + q];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) v[c][q] = norm_u8(px[c], rcp);
+                    for (int c = 0; c < 3; ++c) v[c][q] = norm_u8(px[c], rcp);
+                }
+                const size_t row = (size_t)r * gp * gp + (size_t)(y / P) * gp + (x / P);
+                uint16_t* o = (uint16_t*)out + row * (size_t)(3 * P * P) + (y % P) * P + (x % P);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    *(uint4*)(o + (size_t)c * P * P) = make_uint4(pack_bf16x2(v[c][0], v[c][1]), pack_bf16x2(v[c][2], v[c][3]),
+                                                                  pack_bf16x2(v[c][4], v[c][5]), pack_bf16x2(v[c][6], v[c][7]));
             }
-            const size_t row = (size_t)r * gp * gp + (size_t)(y / P) * gp + (x / P);
-            uint16_t* o = (uint16_t*)out + row * (size_t)(3 * P * P) + (y % P) * P + (x % P);
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                *(uint4*)(o + (size_t)c * P * P) = make_uint4(pack_bf16x2(v[c][0], v[c][1]), pack_bf16x2(v[c][2], v[c][3]),
-                                                              pack_bf16x2(v[c][4], v[c][5]), pack_bf16x2(v[c][6], v[c][7]));
-        }
+        };
+        // (two instantiations so that the staged one reads LDS with ds_read_u8 rather than through a generic pointer)
+        if (staged) run([&](int yl) __attribute__((always_inline)) { return (const uint8_t*)rowbuf[yl] + rshift[yl]; });
+        else run([&](int yl) __attribute__((always_inline)) { return src + (size_t)ty_sh[yl] * (size_t)W * 3; });
         return;
     }
     const int items = rows_per_block * 3 * groups;
