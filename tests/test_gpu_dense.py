@@ -171,6 +171,36 @@ def test_linear_persistent_8phase_exact_integer(yv, M, N, K, kind, rows):
         yv.set_option("linear_p8_rows", 0)
 
 
+def test_linear_persistent_8phase_race_screen(yv):
+    """Short form of tools/p8_race_screen.py (5,120 runs, profiles/r02_p8_race_screen.txt): the persistent kernel must be bit-identical
+    to the round-1 128 x 128 kernel (both sum the K steps in order) on every repetition, for every tile height, at 208 and 256
+    workgroups, with a library GEMM running beside it on a second stream."""
+    g = torch.Generator().manual_seed(0)
+    side = torch.cuda.Stream()
+    noise = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    try:
+        for (m, n, k) in ((12608, 768, 768), (6304, 2304, 768), (2048 + 37, 1536, 128)):
+            a = bf(torch.randn(m, k, generator=g)).to(DEV); w = bf(torch.randn(n, k, generator=g) * 0.05).to(DEV)
+            bias = torch.randn(n, generator=g).to(DEV); res0 = torch.randn(m, n, generator=g).to(DEV)
+            for flags, dt in ((yv.EPI_GELU, torch.bfloat16), (yv.EPI_RES_F32, torch.float32)):
+                def run(variant, cus=0, rows=0):
+                    yv.set_option("linear_variant", variant); yv.set_option("linear_p8_cus", cus); yv.set_option("linear_p8_rows", rows)
+                    out = res0.clone() if flags & yv.EPI_RES_F32 else torch.full((m, n), 3.0, dtype=dt, device=DEV)
+                    yv.linear(a, w, bias, out, flags=flags)
+                    return out
+                ref = run(3)
+                for cus in (0, 208):
+                    for rows in (0, 128, 160, 192):
+                        for r in range(3):
+                            if r & 1:
+                                with torch.cuda.stream(side):
+                                    noise @ noise
+                            assert torch.equal(run(9, cus, rows), ref), (m, n, k, flags, cus, rows, r)
+        torch.cuda.synchronize()
+    finally:
+        yv.set_option("linear_variant", 1); yv.set_option("linear_p8_cus", 0); yv.set_option("linear_p8_rows", 0)
+
+
 def test_gelu_fast_form_accuracy(yv):
     """The sigmoid-form GELU of the persistent kernel against torch's erf GELU on a dense grid of arguments (identity weight:
     the GEMM reproduces its bf16 input exactly): abs error <= 2.5e-5 (fit) + half a bf16 step of the output."""

@@ -159,11 +159,20 @@ __global__ __launch_bounds__(256) void wrapper_head_kernel(const float* __restri
         const int u = tid & (WH_HID - 1), half = tid >> 7;                    // 2 K-halves x 128 units
         const int k0 = half * (WH_FEAT / 2);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int k = k0; k < k0 + WH_FEAT / 2; k += 4) {
-            s0 = fmaf(f[k], w1t[(size_t)k * WH_HID + u], s0);
-            s1 = fmaf(f[k + 1], w1t[(size_t)(k + 1) * WH_HID + u], s1);
-            s2 = fmaf(f[k + 2], w1t[(size_t)(k + 2) * WH_HID + u], s2);
-            s3 = fmaf(f[k + 3], w1t[(size_t)(k + 3) * WH_HID + u], s3);
+        // 20 weight loads in flight per trip (the chain s0..s3 and its order are unchanged: same bits), 25 trips: with 4 loads
+        // per trip the loop was 125 dependent L2 round trips - 28 us for 64 rows at the tail of every classifier pass
+        static_assert((WH_FEAT / 2) % 20 == 0, "trip size");
+        for (int k = k0; k < k0 + WH_FEAT / 2; k += 20) {
+            float w[20];
+#pragma unroll
+            for (int j = 0; j < 20; ++j) w[j] = w1t[(size_t)(k + j) * WH_HID + u];
+#pragma unroll
+            for (int j = 0; j < 20; j += 4) {
+                s0 = fmaf(f[k + j], w[j], s0);
+                s1 = fmaf(f[k + j + 1], w[j + 1], s1);
+                s2 = fmaf(f[k + j + 2], w[j + 2], s2);
+                s3 = fmaf(f[k + j + 3], w[j + 3], s3);
+            }
         }
         part[half][u] = (s0 + s1) + (s2 + s3);
     }
