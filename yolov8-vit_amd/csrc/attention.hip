@@ -72,16 +72,31 @@ __global__ __launch_bounds__(NT * 64, SINGLE ? 4 : 1) void attention_kernel(cons
     for (int kv0 = 0; kv0 < N; kv0 += NP) {
         if (kv0 > 0) __syncthreads();                    // every wave is done reading the previous tile
         // ---- stage K (swizzled rows) and V^T (explicit transpose) -------------------------
-        for (int it = tid; it < NP * 8; it += T) {
-            const int kl = it >> 3, c = it & 7;
-            const int key = kv0 + kl;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (ABL != 1 && key < N) {
-                kv = *(const uint4*)(base + (size_t)key * ld + D + c * 8);
-                vv = *(const uint4*)(base + (size_t)key * ld + 2 * D + c * 8);
+        // All of a thread's K / V chunks are fetched before the first one is stored (NP * 8 / T = 4 trips, 8 loads in flight), from
+        // a CLAMPED row instead of behind `if (key < N)`: rows past N only have to be finite (their scores are masked to -inf,
+        // their probabilities are exactly 0), and a conditional load is a branch + vmcnt(0) per trip - the staging phase of the
+        // first version was 4 dependent HBM round trips per workgroup.
+        constexpr int TRIPS = (NP * 8 + T - 1) / T;
+        uint4 kvr[TRIPS], vvr[TRIPS];
+#pragma unroll
+        for (int i = 0; i < TRIPS; ++i) {
+            const int it = tid + i * T;
+            const int kl = (it < NP * 8 ? it : NP * 8 - 1) >> 3, c = it & 7;
+            int key = kv0 + kl;
+            key = key < N ? key : N - 1;
+            kvr[i] = vvr[i] = make_uint4(0, 0, 0, 0);
+            if (ABL != 1) {
+                kvr[i] = *(const uint4*)(base + (size_t)key * ld + D + c * 8);
+                vvr[i] = *(const uint4*)(base + (size_t)key * ld + 2 * D + c * 8);
             }
-            *(uint4*)(Ks + kl * 128 + ((c ^ ((kl >> 1) & 7)) << 4)) = kv;
-            const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+        }
+#pragma unroll
+        for (int i = 0; i < TRIPS; ++i) {
+            const int it = tid + i * T;
+            if (it >= NP * 8) break;
+            const int kl = it >> 3, c = it & 7;
+            *(uint4*)(Ks + kl * 128 + ((c ^ ((kl >> 1) & 7)) << 4)) = kvr[i];
+            const uint32_t w[4] = {vvr[i].x, vvr[i].y, vvr[i].z, vvr[i].w};
             if (ABL != 3) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
