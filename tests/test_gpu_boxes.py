@@ -334,6 +334,27 @@ def test_crop_resize_norm_bit_exact(yv):
     assert torch.equal(part[:2], f32[:2]) and float(part[2:].abs().sum()) == 0
 
 
+def test_crop_wide_sources_both_gather_paths(yv):
+    """Camera-sized sources (1080 x 1920, a row is not a multiple of 8 bytes): crops narrower than 677 pixels go through the
+    LDS-staged gather (aligned 8-byte loads around arbitrary byte offsets, first / last pixel of the buffer included), wider
+    ones through the direct global gather; both bit for bit against the oracle, all three layouts."""
+    H, W = 1080, 1921
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randint(0, 256, (2, H, W, 3), generator=g, dtype=torch.uint8)
+    rects = [(0, 0, 0, 1921, 1080, 0), (1, 1200, 1000, 1921, 1080, 0), (0, 0, 0, 677, 5, 0), (1, 1, 1, 679, 400, 0),
+             (1, 1244, 3, 1921, 1080, 0), (0, 1920, 1079, 1921, 1080, 0), (1, 1913, 1070, 1921, 1080, 0), (0, 0, 0, 1, 1, 0),
+             (1, 333, 777, 1009, 1011, 0), (0, 5, 5, 683, 300, 0)]
+    cl = torch.tensor(rects, dtype=torch.int32, device=DEV)
+    tot = torch.tensor([len(rects)], dtype=torch.int32, device=DEV)
+    dimg = imgs.to(DEV)
+    f32 = yv.crop_resize_norm(dimg, cl, tot, len(rects), 224, 16, layout=0).cpu()
+    pm = yv.crop_resize_norm(dimg, cl, tot, len(rects), 224, 16, layout=2).cpu()
+    for r, rc in enumerate(rects):
+        exp = ob.crop_resize_normalize(imgs[rc[0]].numpy(), rc[1:5])
+        assert np.array_equal(f32[r].numpy(), exp), r
+        assert torch.equal(pm[r * 196:(r + 1) * 196], torch.from_numpy(ob.patchify(exp, 16)).to(torch.bfloat16)), r
+
+
 def test_crop_gather_at_bench_batch(yv):
     """The crop gather at the post-processing bench's full size (256 images of 640 x 640, 1024 crops, patch-major bf16): 24
     crops sampled across the batch bit for bit against the oracle; for every crop the three layouts must hold the same
