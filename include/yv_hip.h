@@ -217,8 +217,9 @@ typedef struct yv_view {
  * out = (B,Hout,Wout,*) view with pixel stride out_ld (bf16, or f32 with YV_EPI_OUT_F32);
  * res = optional bf16 residual view (same pixel grid as out).
  * Limits: the fused 2x upsample (yv_view.up) is a property of 1x1 inputs (YV_ERR_ARG with ksize 3); the kernel
- * addresses each source and the weights with 32-bit byte offsets: B*Hin*Win*ld*2 and Cout*k*k*Cin*2 must stay
- * below 2 GB (YV_ERR_LIMIT). */
+ * addresses each source and the weights with 32-bit byte offsets: a batch whose source passes 2 GB is taken in
+ * sub-batches by this entry, one IMAGE (Hin*Win*ld*2) and the weights (Cout*k*k*Cin*2) must stay below 2 GB
+ * (YV_ERR_LIMIT). */
 int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
               const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res, int res_ld,
               int flags, void* stream);

@@ -272,6 +272,31 @@ def test_conv_concat_upsample_residual(yv):
     assert rel_l2(buf[..., 32:48].permute(0, 3, 1, 2).float().cpu(), ref3) < 4e-3
 
 
+def test_conv_sources_beyond_2gb_are_subbatched(yv):
+    """The conv kernel addresses a source with 32-bit byte offsets; a batch whose source tensor passes 2 GB (here 40 images of
+    320 x 320 pixels at a pixel stride of 336 channels = 2.75 GB) is taken in sub-batches by the host: results must equal the same
+    convolution over a compact copy of the 16 channels that are read (3 x 3 / stride 2 and 1 x 1 with a bf16 shortcut)."""
+    B, H, ld, c = 40, 320, 336, 16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    big = torch.randn(B, H, H, ld, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    assert big.numel() * 2 > 2 ** 31
+    small = big[..., 8:8 + c].contiguous()
+    gc = torch.Generator().manual_seed(4)
+    w3 = bf(torch.randn(32, 3, 3, c, generator=gc) * 0.1).reshape(32, 9 * c).contiguous().to(DEV); b3 = (torch.randn(32, generator=gc) * 0.1).to(DEV)
+    w1 = bf(torch.randn(16, c, generator=gc) * 0.2).contiguous().to(DEV); b1 = (torch.randn(16, generator=gc) * 0.1).to(DEV)
+    for (k, s_, w, b_, co) in ((3, 2, w3, b3, 32), (1, 1, w1, b1, 16)):
+        Ho = H // s_
+        out_big = torch.zeros(B, Ho, Ho, co, dtype=torch.bfloat16, device=DEV)
+        out_small = torch.zeros_like(out_big)
+        res = (big, 8) if k == 1 else (None, 0)
+        res_s = (small, 0) if k == 1 else (None, 0)
+        fl = yv.EPI_SILU | (yv.EPI_RES_BF16 if k == 1 else 0)
+        yv.conv2d(yv.view(big, 8, c), None, B, Ho, Ho, k, s_, w, b_, out_big, 0, fl, res=res[0], res_c_off=res[1])
+        yv.conv2d(yv.view(small, 0, c), None, B, Ho, Ho, k, s_, w, b_, out_small, 0, fl, res=res_s[0], res_c_off=res_s[1])
+        assert torch.equal(out_big, out_small), k
+        assert float(out_big[-1].float().abs().sum()) > 0
+
+
 def test_layernorm(yv):
     g = torch.Generator().manual_seed(1)
     for D, rows in ((768, 197 * 2), (1024, 33), (128, 10)):

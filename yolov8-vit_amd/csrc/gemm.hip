@@ -1943,9 +1943,9 @@ extern "C" int yv_linear_ex(const void* A, int lda, const void* W, const float* 
                        (hipStream_t)stream);
 }
 
-static int conv_impl(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
-                     const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res,
-                     int res_ld, int flags, void* ws, size_t ws_bytes, void* stream) {
+static int conv_impl_one(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
+                         const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res,
+                         int res_ld, int flags, void* ws, size_t ws_bytes, void* stream) {
     if (!in0 || !in0->ptr || !weight || !out || B <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0) return YV_ERR_ARG;
     if (!(ksize == 1 || ksize == 3) || !(stride == 1 || stride == 2)) return YV_ERR_ARG;
     if (in1 && in1->ptr && ksize != 1) return YV_ERR_ARG;
@@ -1992,6 +1992,41 @@ static int conv_impl(const yv_view* in0, const yv_view* in1, int B, int Hout, in
         }
     }
     return dispatch<1>(g, (hipStream_t)stream);
+}
+
+// The kernel addresses each source with 32-bit byte offsets (< 2 GB): larger batches are taken in sub-batches, images being
+// independent (e.g. the 48-channel C2f buffer of YOLOv8n at 320 x 320 passes 2 GB at 218 images).
+static int conv_impl(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,
+                     const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res,
+                     int res_ld, int flags, void* ws, size_t ws_bytes, void* stream) {
+    if (!in0 || !in0->ptr || B <= 0 || Hout <= 0 || Wout <= 0 || !out)
+        return conv_impl_one(in0, in1, B, Hout, Wout, ksize, stride, weight, bias, Cout, out, out_ld, res, res_ld, flags, ws, ws_bytes,
+                             stream);
+    const long long Hin = (long long)Hout * stride, Win = (long long)Wout * stride;
+    const bool two = in1 && in1->ptr;
+    const long long s0 = (Hin >> in0->up) * (Win >> in0->up) * in0->ld * 2;
+    const long long s1 = two ? (Hin >> in1->up) * (Win >> in1->up) * in1->ld * 2 : 0;
+    const long long lead = (Win + 1) * in0->ld * 2;
+    const long long cap = 0x7ffffff0LL;
+    long long nb = s0 > 0 ? (cap - lead) / s0 : B;
+    if (two && s1 > 0 && cap / s1 < nb) nb = cap / s1;
+    if (nb >= B)
+        return conv_impl_one(in0, in1, B, Hout, Wout, ksize, stride, weight, bias, Cout, out, out_ld, res, res_ld, flags, ws, ws_bytes,
+                             stream);
+    if (nb < 1) return YV_ERR_LIMIT;                              // a single image beyond 2 GB
+    const long long esz = (flags & YV_EPI_OUT_F32) ? 4 : 2;
+    for (long long b0 = 0; b0 < B; b0 += nb) {
+        const int n = (int)(B - b0 < nb ? B - b0 : nb);
+        yv_view v0 = *in0, v1 = two ? *in1 : yv_view{};
+        v0.ptr = (unsigned char*)in0->ptr + b0 * s0;
+        if (two) v1.ptr = (unsigned char*)in1->ptr + b0 * s1;
+        const int rc = conv_impl_one(&v0, two ? &v1 : nullptr, n, Hout, Wout, ksize, stride, weight, bias, Cout,
+                                     (unsigned char*)out + b0 * Hout * Wout * out_ld * esz, out_ld,
+                                     res ? (const unsigned char*)res + b0 * Hout * Wout * res_ld * 2 : nullptr, res_ld, flags, ws, ws_bytes,
+                                     stream);
+        if (rc != YV_OK) return rc;
+    }
+    return YV_OK;
 }
 
 extern "C" int yv_linear_nn(const void* A, int lda, const void* Wkn, int ldw, const float* bias, int M, int N, int K,
