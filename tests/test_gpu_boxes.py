@@ -213,6 +213,17 @@ def test_efficient_nms_clustered_boxes_and_small_limits(yv):
             got = yv.efficient_nms(boxes.to(DEV), scores.to(DEV), thr, iou, mo, topk, single_kernel=sk)
             for e, g_ in zip(exp, got):
                 assert torch.equal(e, g_.cpu()), (thr, iou, mo, topk, sk)
+    # the same clusters with 12 classes: the per-class / merge pair of launches (more than 8 classes) on a segmented candidate
+    # list (24,000 scores per image), images the head cannot finish, classes without candidates
+    nc2 = 12
+    s12 = torch.rand(B, A, nc2, generator=g) ** 3
+    s12[:, :, 7] = 0.0                                                 # an empty class
+    for thr, iou, mo, topk in ((0.5, 0.5, 100, 4096), (0.2, 0.65, 100, 4096), (0.7, 0.3, 50, 600)):
+        exp = ob.efficient_nms(boxes, s12, thr, iou, mo, topk)
+        for sk in (False, True):
+            got = yv.efficient_nms(boxes.to(DEV), s12.to(DEV), thr, iou, mo, topk, single_kernel=sk)
+            for e, g_ in zip(exp, got):
+                assert torch.equal(e, g_.cpu()), (thr, iou, mo, topk, sk)
     bb, ss = _rand_dets(64, 8400, 5, 4242)
     a = yv.efficient_nms(bb.to(DEV), ss.to(DEV))
     b = yv.efficient_nms(bb.to(DEV), ss.to(DEV), single_kernel=True)

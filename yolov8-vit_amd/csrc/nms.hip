@@ -354,6 +354,7 @@ __global__ __launch_bounds__(EN_THREADS) void efficient_nms_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int EN2_FT = 256;                 // filter: threads per workgroup
 constexpr int EN2_FPT = 16;                 // filter: scores per thread  -> 4096 scores per workgroup
+constexpr int EN2_SEGS = 11;                // chunks per image in segmented mode (44 K scores)
 constexpr int EN2_CC_LDS = 2048;            // per-class counters staged in LDS up to this many classes
 
 struct En2Ws {                              // device pointers into the caller's workspace (see yv_efficient_nms_ws_bytes)
@@ -364,6 +365,8 @@ struct En2Ws {                              // device pointers into the caller's
     uint32_t* ccount;                       // (B, nc)  candidates per class (of the selected set)
     uint32_t* nkept;                        // (B, nc)
     uint32_t* done;                         // (B)      1: the head produced the image's final outputs
+    uint32_t* seg;                          // (B, EN2_SEGS) segmented mode: candidates of each 4096-score chunk of the image
+    int nseg;                               // > 0: segmented mode with this many chunks per image (see en2_filter_kernel)
 };
 
 __device__ __forceinline__ float key_score(uint32_t key) {          // inverse of desc_key
@@ -406,7 +409,15 @@ __global__ __launch_bounds__(EN2_FT) void en2_filter_kernel(const float* __restr
     uint32_t before = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < EN2_FT / 64; ++w) { const uint32_t c = wave_cnt[w]; if (w < wave) before += c; tot += c; }
-    if (tid == 0) base_sh = tot ? atomicAdd(&ws.count[b], tot) : 0u;
+    // SEGMENTED mode (images of up to 44 K scores, i.e. any detector-sized problem): the chunk's candidates go to the chunk's own
+    // 4096-entry region of the list and its count to seg[b][chunk] - plain stores, nothing to zero beforehand, so the call needs
+    // no memset launch in front (a dependent launch costs ~4 us of a ~32 us call); per-class counts are left to the general
+    // path.  Otherwise: one list per image through an atomic counter that the caller's memset zeroed.
+    const bool segm = ws.nseg > 0;
+    if (tid == 0) {
+        if (segm) { ws.seg[(size_t)b * EN2_SEGS + blockIdx.x] = tot; base_sh = blockIdx.x * (EN2_FT * EN2_FPT); }
+        else base_sh = tot ? atomicAdd(&ws.count[b], tot) : 0u;
+    }
     __syncthreads();
     if (tot == 0) return;
     uint32_t pos = base_sh + before + (incl - mine);
@@ -417,14 +428,27 @@ __global__ __launch_bounds__(EN2_FT) void en2_filter_kernel(const float* __restr
         if (i < total && v[j] > thr) {
             if (pos < (uint32_t)ws.lcap) list[pos] = ((uint64_t)desc_key(v[j]) << 32) | (uint32_t)i;
             ++pos;
-            const uint32_t c = (uint32_t)i % (uint32_t)nc;
-            if (cc_lds) atomicAdd(&cc[c], 1u); else atomicAdd(&ws.ccount[(size_t)b * nc + c], 1u);
+            if (!segm) {
+                const uint32_t c = (uint32_t)i % (uint32_t)nc;
+                if (cc_lds) atomicAdd(&cc[c], 1u); else atomicAdd(&ws.ccount[(size_t)b * nc + c], 1u);
+            }
         }
     }
-    if (cc_lds) {
+    if (cc_lds && !segm) {
         __syncthreads();
         for (int c = tid; c < nc; c += EN2_FT) { const uint32_t n = cc[c]; if (n) atomicAdd(&ws.ccount[(size_t)b * nc + c], n); }
     }
+}
+
+// segmented list: candidate number g of the image (chunks in order) sits at list[g + shift of its chunk]; pre[s] = candidates in
+// the chunks before s, dlt[s] = s * 4096 - pre[s] (uniform values; chunk 0 has shift 0)
+struct SegMap { uint32_t pre[EN2_SEGS], dlt[EN2_SEGS]; int nseg; };
+__device__ __forceinline__ uint32_t seg_index(const SegMap& m, uint32_t g) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int sgi = 1; sgi < EN2_SEGS; ++sgi)
+        if (sgi < m.nseg && g >= m.pre[sgi]) d = m.dlt[sgi];
+    return g + d;
 }
 
 // images with more than K candidates: exact selection of the K best (score desc, flat asc), rewritten into the list.
@@ -680,7 +704,7 @@ struct HeadLds {                            // (one instance in the kernel: the 
 template <int NR>
 __device__ __forceinline__ bool en2_head_body(const float* __restrict__ boxes, const float* __restrict__ scores, int A, int nc,
                                               float iou_thr, int max_out, int K, const En2Ws& ws, int b, uint32_t cnt,
-                                              SelLds& L, HeadLds& H, unsigned char* dyn, int32_t* __restrict__ num_dets,
+                                              const SegMap& sm, SelLds& L, HeadLds& H, unsigned char* dyn, int32_t* __restrict__ num_dets,
                                               float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                               int32_t* __restrict__ out_labels) {
     uint64_t (&keys)[EN2_HEAD] = H.keys;
@@ -702,7 +726,7 @@ __device__ __forceinline__ bool en2_head_body(const float* __restrict__ boxes, c
 #pragma unroll
     for (int c = 0; c < NR; ++c) {
         const uint32_t i = (uint32_t)(c * EN_THREADS + tid);
-        kreg[c] = i < cnt ? ((const uint32_t*)list)[2 * i + 1] : 0xFFFFFFFFu;       // (the key is the high word of the entry)
+        kreg[c] = i < cnt ? ((const uint32_t*)list)[2 * seg_index(sm, i) + 1] : 0xFFFFFFFFu;     // (the key is the high word of the entry)
     }
     for (int i = tid; i < 16 * 256; i += EN_THREADS) (&L.hist[0][0])[i] = 0;     // (for the first histogram pass, under the loads)
     const uint32_t head = (uint32_t)(K < EN2_HEAD ? K : EN2_HEAD);
@@ -789,7 +813,7 @@ __device__ __forceinline__ bool en2_head_body(const float* __restrict__ boxes, c
     uint32_t pos = block_excl_scan(n_le, L, n);
 #pragma unroll
     for (int c = 0; c < NR; ++c)
-        if (kreg[c] <= key_star) { if (pos < (uint32_t)EN2_HEAD) tmpk[pos] = list[c * EN_THREADS + tid]; ++pos; }
+        if (kreg[c] <= key_star) { if (pos < (uint32_t)EN2_HEAD) tmpk[pos] = list[seg_index(sm, (uint32_t)(c * EN_THREADS + tid))]; ++pos; }
     if (tid < EN2_HEAD) rank[tid] = 0;
     n = n < (uint32_t)EN2_HEAD ? n : (uint32_t)EN2_HEAD;        // (n == head when cnt > head, else cnt)
     if (tid >= (int)n && tid < EN2_HEAD) tmpk[tid] = ~0ull;     // sentinels: never "before" a key, so the count loop needs no bound
@@ -1024,15 +1048,53 @@ __global__ __launch_bounds__(EN_THREADS) void en2_front_kernel(const float* __re
     __shared__ uint32_t n_heavy;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];     // en2_one_class<EN_MAXK> (covers the head's kept boxes)
     const int b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t cnt = ws.count[b];
+    SegMap sm;
+    sm.nseg = ws.nseg;
+    uint32_t cnt = 0;
+    if (ws.nseg > 0) {                                         // segmented list: per-chunk counts -> prefix sums (uniform)
+#pragma unroll
+        for (int sgi = 0; sgi < EN2_SEGS; ++sgi) {
+            const uint32_t n = sgi < ws.nseg ? ws.seg[(size_t)b * EN2_SEGS + sgi] : 0u;
+            sm.pre[sgi] = cnt;
+            sm.dlt[sgi] = (uint32_t)(sgi * (EN2_FT * EN2_FPT)) - cnt;
+            cnt += n;
+        }
+    } else {
+#pragma unroll
+        for (int sgi = 0; sgi < EN2_SEGS; ++sgi) { sm.pre[sgi] = 0; sm.dlt[sgi] = 0; }
+        cnt = ws.count[b];
+    }
     bool done = false;                                         // (cnt beyond the list capacity: general path)
     if (cnt <= (uint32_t)(EN2_HR * EN_THREADS))
-        done = en2_head_body<EN2_HR>(boxes, scores, A, nc, iou_thr, max_out, K, ws, b, cnt, L, H, dyn, num_dets, out_boxes,
+        done = en2_head_body<EN2_HR>(boxes, scores, A, nc, iou_thr, max_out, K, ws, b, cnt, sm, L, H, dyn, num_dets, out_boxes,
                                      out_scores, out_labels);
     else if (cnt <= (uint32_t)ws.lcap)
-        done = en2_head_body<EN2_HRW>(boxes, scores, A, nc, iou_thr, max_out, K, ws, b, cnt, L, H, dyn, num_dets, out_boxes,
+        done = en2_head_body<EN2_HRW>(boxes, scores, A, nc, iou_thr, max_out, K, ws, b, cnt, sm, L, H, dyn, num_dets, out_boxes,
                                       out_scores, out_labels);
     if (done) return;
+    __syncthreads();
+    if (ws.nseg > 0) {
+        // nothing was zeroed for this call: leave what the memset + atomic filter would have left for the general path
+        if (tid == 0) { ws.count[b] = cnt; ws.done[b] = 0u; }
+        if (cnt <= (uint32_t)K) {
+            // the list becomes contiguous in place: chunk 0's candidates stay, the others move down behind them - into chunk 0's
+            // own region (cnt <= K <= 4096 entries), which no other chunk's candidates occupy
+            uint64_t* list = ws.cand + (size_t)b * ws.lcap;
+            const bool cc_lds = nc <= EN2_CC_LDS;
+            if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) cc[c] = 0;
+            else for (int c = tid; c < nc; c += EN_THREADS) ws.ccount[(size_t)b * nc + c] = 0;
+            __syncthreads();
+            for (uint32_t gi = tid; gi < cnt; gi += EN_THREADS) {
+                const uint64_t k = list[seg_index(sm, gi)];
+                if (gi >= sm.pre[1]) list[gi] = k;             // (ws.nseg == 1: pre[1] = cnt, nothing moves)
+                const uint32_t cl = (uint32_t)k % (uint32_t)nc;
+                if (cc_lds) atomicAdd(&cc[cl], 1u); else atomicAdd(&ws.ccount[(size_t)b * nc + cl], 1u);
+            }
+            __syncthreads();
+            if (cc_lds) for (int c = tid; c < nc; c += EN_THREADS) ws.ccount[(size_t)b * nc + c] = cc[c];
+            __threadfence_block();                             // list / counts are read back below (coherent loads)
+        }
+    }
     __syncthreads();
     if (cnt > (uint32_t)K) {                                   // else the list already is the selected set
         en2_select_body(scores, A, nc, score_thr, K, ws, b, L, cc);
@@ -1060,7 +1122,8 @@ __global__ __launch_bounds__(256) void en2_classes_kernel(const float* __restric
     const int c = blockIdx.x, b = blockIdx.y;
     if (ws.done[b]) return;
     const uint32_t n_c = ws.ccount[(size_t)b * nc + c];
-    if (n_c == 0 || n_c > 1024u) return;                       // nkept was zeroed by the memset node of this call
+    if (n_c == 0 && threadIdx.x == 0) ws.nkept[(size_t)b * nc + c] = 0;        // (segmented mode: no memset zeroed it)
+    if (n_c == 0 || n_c > 1024u) return;
     en2_one_class<1024, 256>(smem, boxes, A, nc, c, b, iou_thr, max_out, K, ws);
 }
 
@@ -1077,6 +1140,7 @@ __global__ __launch_bounds__(1024) void en2_tail_kernel(const float* __restrict_
     if (ws.done[b]) return;
     for (int c = 0; c < nc; ++c) {
         const uint32_t n_c = ws.ccount[(size_t)b * nc + c];    // (uniform; written by earlier launches)
+        if (n_c == 0 && threadIdx.x == 0) ws.nkept[(size_t)b * nc + c] = 0;     // (segmented mode: no memset zeroed it)
         if (n_c == 0 || n_c > 1024u) continue;                 // heavy classes were done by en2_front_kernel
         en2_one_class<1024, 1024>(smem, boxes, A, nc, c, b, iou_thr, max_out, K, ws);
     }
@@ -1300,7 +1364,8 @@ extern "C" int yv_efficient_nms(const float* boxes, const float* scores, int B, 
 // scores), never less than pre_topk, never more than there are scores
 static int en2_lcap(int A, int nc, int K) {
     const long long total = (long long)A * nc;
-    long long c = total < (long long)EN2_HRW * EN_THREADS ? total : (long long)EN2_HRW * EN_THREADS;
+    // up to 44 K scores per image: one 4096-entry region per filter chunk (segmented mode); beyond: the 44 K best-effort list
+    long long c = total <= (long long)EN2_HRW * EN_THREADS ? (total + 4095) / 4096 * 4096 : (long long)EN2_HRW * EN_THREADS;
     if (c < K) c = K;
     return (int)((c + 63) & ~63LL);
 }
@@ -1312,11 +1377,12 @@ static size_t en2_layout(int B, int A, int nc, int max_out, int K, En2Ws* w, uns
     const size_t o_count = take((size_t)B * 4), o_cc = take((size_t)B * nc * 4), o_nk = take((size_t)B * nc * 4);
     const size_t o_done = take((size_t)B * 4);
     if (zero_bytes) *zero_bytes = off;
+    const size_t o_seg = take((size_t)B * EN2_SEGS * 4);
     const int lcap = en2_lcap(A, nc, K);
     const size_t o_cand = take((size_t)B * lcap * 8), o_kept = take((size_t)B * nc * max_out * 8);
     if (w && base) {
         w->count = (uint32_t*)(base + o_count); w->ccount = (uint32_t*)(base + o_cc); w->nkept = (uint32_t*)(base + o_nk);
-        w->done = (uint32_t*)(base + o_done);
+        w->done = (uint32_t*)(base + o_done); w->seg = (uint32_t*)(base + o_seg); w->nseg = 0;
         w->cand = (uint64_t*)(base + o_cand); w->kept = (uint64_t*)(base + o_kept); w->lcap = lcap;
     }
     return off;
@@ -1342,9 +1408,11 @@ extern "C" int yv_efficient_nms_ws(const float* boxes, const float* scores, int 
     const size_t need = en2_layout(B, A, nc, max_out, pre_topk, &w, (unsigned char*)ws, &zero_bytes);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) return YV_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, zero_bytes, st) != hipSuccess) return YV_ERR_LAUNCH;
     const int total = A * nc;
     const int chunks = (total + EN2_FT * EN2_FPT - 1) / (EN2_FT * EN2_FPT);
+    // segmented candidate lists (no counter to zero, no memset launch) whenever an image is at most EN2_SEGS chunks
+    w.nseg = chunks <= EN2_SEGS && (long long)chunks * (EN2_FT * EN2_FPT) <= w.lcap ? chunks : 0;
+    if (!w.nseg && hipMemsetAsync(ws, 0, zero_bytes, st) != hipSuccess) return YV_ERR_LAUNCH;
     hipLaunchKernelGGL(en2_filter_kernel, dim3(chunks, B), dim3(EN2_FT), 0, st, scores, total, nc, score_threshold, pre_topk, w);
     auto lds_of = [&](int cap, int nw) { return (size_t)cap * (8 + 16) + (size_t)max_out * 16 + 128 * 8 + (size_t)nw * 8 + 16; };
     const size_t head_dyn = (size_t)max_out * (16 + 8 + 2) + 16;
