@@ -250,6 +250,44 @@ def launch_ranks(n: int) -> int:
     return max(abs(c) for c in codes)
 
 
+def live_traffic(argv_tail):
+    """HBM-side bytes per launch of the dominant kernel, measured NOW: two short child runs of this very command under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (their own passes, with --kernel-trace only), started before this process
+    has touched the GPU.  bytes = 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE reads half of a wide
+    coalesced read stream) + WRITE_SIZE, averaged over the kernel's dispatches.  None if the profiler is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="yv_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__)] + argv_tail + ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
+            if r.returncode != 0:
+                return None
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                rows += [float(x["Counter_Value"]) for x in csv.DictReader(open(f))
+                         if DOMINANT_KERNEL in x["Kernel_Name"] and x["Counter_Name"] == counter]
+            if not rows:
+                return None
+            vals[counter] = (sum(rows) / len(rows), len(rows))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"bytes_per_launch": (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0,
+            "launches": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +296,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--crops", type=int, default=4, help="crops classified per image (cap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic live (two short rocprofv3 --pmc child runs before the timed run)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no detector/classifier overlap across batches")
     ap.add_argument("--no-split", action="store_true", help="keep the classifier of a batch on one stream (no half-batch overlap)")
     ap.add_argument("--models", choices=["base", "large"], default="base",
@@ -281,6 +321,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    live = None
+    if (args.mode == "infer" and args.models == "base" and args.dtype == "bf16" and world == 1 and "RANK" not in os.environ
+            and not args.no_traffic and os.environ.get("YV_BENCH_DRY") != "1"):
+        # before this process initialises HIP (importing torch and counting devices does not): the children are started, never exec'ed
+        tail = [a for f in ("--batch", "--crops") for a in (f, str(getattr(args, f[2:])))]
+        tail += [f for f, on in (("--no-overlap", args.no_overlap), ("--no-split", args.no_split)) if on]
+        live = live_traffic(tail)
     if os.environ.get("YV_BENCH_DRY") == "1":        # launcher test (tests/test_dist_cpu.py): report the rank layout, touch no GPU
         print(json.dumps({"rank": rank, "world": world, "local": local, "gpus": args.gpus}), flush=True)
         return 0
@@ -372,13 +419,18 @@ def main():
         # HBM bytes per launch of the dominant kernel come from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command
         # (tools/profile_summary.py -> profiles/pmc_traffic.json).  The file names the kernel and the round it was collected
         # for; anything else (other kernel, older round) is reported as null instead of a stale number.
-        traffic = None
+        traffic, traffic_source = None, None
+        if live is not None:
+            traffic = live["bytes_per_launch"]
+            traffic_source = (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command before the timed run, "
+                              f"{live['launches'][0]} / {live['launches'][1]} dispatches; 2 x FETCH + WRITE")
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.dtype == "bf16" and not large:
+        if traffic is None and os.path.exists(pmc) and args.dtype == "bf16" and not large:
             try:
                 tj = json.load(open(pmc))
                 if tj.get("kernel") == DOMINANT_KERNEL and tj.get("round") == ROUND_TAG:
                     traffic = tj.get("bytes_per_launch")
+                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 passes of this round over this command)"
             except Exception:
                 traffic = None
         line = {
@@ -402,7 +454,7 @@ def main():
                                ("" if runner is None else ", 208 of 256 CUs (the rest stay free for the concurrent streams)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS * (2.0 if args.dtype == "mxfp8" else 1.0),
                          "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_TFLOPS * (2.0 if args.dtype == "mxfp8" else 1.0)),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ("gemm_p8_kernel (qkv / proj / fc1 / fc2) + gemm_dma_kernel<128,128> (patch-embed, head)" if args.dtype == "bf16" else
                                     "gemm_mx_kernel<128,128> (block linears, block-scaled MFMA peak) + gemm_dma_kernel (patch-embed, head)"),
                          "launches": n_launch,
