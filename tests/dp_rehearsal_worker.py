@@ -1,7 +1,9 @@
 """Rank process of tests/test_gpu_dp.py (not a test module).  Two of these run side by side on cuda:0 with the gloo
 backend (RCCL refuses two ranks on one device): each takes its half of a seeded batch through `steps` VitTrainer steps -
 forward, backward, bucketed gradient all-reduce launched from inside backward, SGD with the 1/world mean folded in - and
-writes its final parameters to `out`.  Usage: python dp_rehearsal_worker.py <model> <R_total> <steps> <out.pt>"""
+writes its final parameters to `out`.  Usage: python dp_rehearsal_worker.py <model> <R_total> <steps> <out.pt> [backend]
+With backend "nccl" and WORLD_SIZE=1 (tests/test_gpu_dp.py::test_rccl_single_rank_step_is_bitwise_the_plain_step) the one rank
+runs the same steps over RCCL with the collectives forced on (YV_DP_FORCE_COLLECTIVE=1)."""
 import os
 import sys
 
@@ -27,9 +29,13 @@ def make_batch(name: str, R: int):
 
 def main():
     name, R, steps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from yvhip.dist import shard_range
     from yvhip.training import VitTrainer
     sd, patches, labels, tok = make_batch(name, R)

@@ -77,3 +77,47 @@ def test_two_rank_step_equals_union_batch_step(tmp_path, name, R, steps):
     for s_ in range(steps):
         m = 0.5 * (ranks[0]["losses"][s_] + ranks[1]["losses"][s_])
         assert abs(m - losses[s_]) < 2e-2 * max(1.0, abs(losses[s_])), (s_, m, losses[s_])
+
+
+def test_rccl_single_rank_step_is_bitwise_the_plain_step(tmp_path):
+    """De-risks the first real multi-GPU run on a one-GPU box: a FRESH child process initialises the `nccl` (= RCCL) backend
+    with WORLD_SIZE=1 exactly as bench.py does (`init_process_group("nccl", device_id=cuda:0)`) and runs VitTrainer steps
+    with the BucketReducer forced active - RCCL library load and communicator set-up, the asynchronous all-reduce launched
+    from the weight-gradient side stream inside backward, and the handle waits against the trainer's two streams all
+    execute.  A SUM over one rank is the identity, so parameters, gradients and losses must equal the no-group run of this
+    process BIT FOR BIT; a stream-ordering bug (a bucket reduced before its gradients are final, SGD before a bucket has
+    landed) would show as a difference."""
+    sys.path.insert(0, HERE)
+    from dp_rehearsal_worker import make_batch
+    from yvhip.training import VitTrainer
+    name, R, steps = "vit_base_patch16_224", 4, 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "rccl.pt")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               YV_DP_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.Popen([sys.executable, os.path.join(HERE, "dp_rehearsal_worker.py"), name, str(R), str(steps), out,
+                             "nccl"], env=env)
+    sd, patches, labels, tok = make_batch(name, R)
+    tr = VitTrainer(sd, name, 5, device="cuda:0", bucket_mb=32.0)
+    pm, lb = patches.to("cuda:0"), labels.to("cuda:0")
+    losses, grads = [], []
+    for _ in range(steps):
+        tr.forward(pm, R)
+        loss = tr.backward(pm, lb, R)
+        torch.cuda.synchronize()
+        grads.append({k: v.cpu() for k, v in tr.grad_dict().items()})
+        tr.optimizer_step(0.01)
+        losses.append(float(loss[0]))
+    torch.cuda.synchronize()
+    plain = {k: v.cpu() for k, v in tr.state_dict().items()}
+    assert proc.wait(timeout=900) == 0
+    got = torch.load(out, weights_only=True)
+    assert got["buckets"] >= 10, got["buckets"]                  # 347 MB of gradients in 32 MB buckets, launched inside backward
+    assert got["losses"] == losses, (got["losses"], losses)
+    for s_ in range(steps):
+        for k in sd:
+            assert torch.equal(got["grads"][s_][k], grads[s_][k]), (s_, k)
+    for k in sd:
+        assert torch.equal(got["state"][k], plain[k]), k

@@ -46,8 +46,6 @@ static bool ws_lookup(void* stream, void** ws, size_t* bytes) {
 }
 int g_opt_linear_splitk = 1;
 int g_opt_splitk = 0;           // measured neutral end-to-end (tools/e2e_ab.py): the reduce pass costs what the shorter chain saves
-int g_opt_wide_min = 1 << 30, g_opt_wide_max = 1 << 30; // N range that takes the 8-phase 256x256 kernel (off by
-                                                          // default: end-to-end A/B, tools/e2e_ab.py, favours 128x128)
 constexpr int THREADS = 256;
 
 struct GemmArgs {
@@ -997,8 +995,9 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const uint16_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// 256 x 256 x 64 "8-phase" kernel (cdna_hip_programming.md section 5 template, re-derived for this operand
-// convention).  8 waves = 2 groups (wm = 0/1, 128 activation rows each) x 4 (64 weight rows each); one
+// 256 x 256 x 64 "8-phase" schedule (cdna_hip_programming.md section 5 template, re-derived for this operand
+// convention; the non-persistent round-1 kernel of this shape was removed in round 3, gemm_p8_kernel below is its
+// persistent form).  8 waves = 2 groups (wm = 0/1, 128 activation rows each) x 4 (64 weight rows each); one
 // workgroup per CU, 128 KB of LDS = 2 stages x {A tile, W tile}.  A K tile is consumed in 4 phases, one
 // 64 x 32 quadrant of the wave tile each (16 MFMAs): (m0,n0) (m0,n1) (m1,n1) (m1,n0); every phase is
 //     [ds_read this phase's operand half | issue ONE half-tile of LDS-DMA] barrier [16 MFMA] barrier
@@ -1016,158 +1015,9 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const uint16_t* __restric
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, MF = 8, NF = 4;
-    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    int M = g.M;
-    if (g.m_dev) { long long md = (long long)g.m_dev[0] * g.m_mul; M = md < M ? (int)md : M; }
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-    }
-    int tm, tn;
-    {
-        const int GM = g.group_m, per = GM * g.tiles_n;
-        const int grp = bid / per, first = grp * GM;
-        const int gsz = (g.tiles_m - first) < GM ? (g.tiles_m - first) : GM;
-        const int in = bid - grp * per;
-        tm = first + in % gsz;
-        tn = in / gsz;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    if (m0 >= M) return;
-
-    const int wm = wave >> 2, wn = wave & 3;
-    const int wrow_m = wm * 128, wrow_n = wn * 64;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int lrow = lane >> 3, lch = lane & 7;
-
-    // ---- DMA descriptors: 4 half-tile kinds x 2 wave-instructions (8 rows x 128 B each) -------------------------
-    const uint16_t* src[4][2];        // [A0, A1, W0, W1][j]
-    int dst[4][2];                    // byte offset inside a stage
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rh = (wave * 2 + j) * 8 + lrow;                    // row inside the 128-row half-tile
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ra = (rh >> 6) * 128 + h * 64 + (rh & 63);     // A tile row
-            int m = m0 + ra;
-            m = m < g.M ? m : g.M - 1;
-            src[h][j] = g.a0 + (long long)m * g.lda0 + ((lch ^ (ra & 7)) << 3);
-            dst[h][j] = (ra - lrow) * 128;
-            const int rw = (rh >> 5) * 64 + h * 32 + (rh & 31);      // W tile row
-            int n = n0 + rw;
-            n = n < g.N ? n : g.N - 1;
-            src[2 + h][j] = g.w + (long long)n * g.K + ((lch ^ (rw & 7)) << 3);
-            dst[2 + h][j] = A_BYTES + (rw - lrow) * 128;
-        }
-    }
-    const int nk = g.K / BK;
-    auto dma = [&](int kind, int kt) {               // one half-tile of K tile kt into stage kt & 1
-        if (kt >= nk) return;
-        unsigned char* base = smem + (kt & 1) * STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][j] + kt * BK), (lptr_t)(base + dst[kind][j]), 16, 0, 0);
-    };
-
-    f32x4 acc[NF][MF];
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-#pragma unroll
-        for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[4][2];                  // current activation half: 4 fragments x 2 k-steps
-    bf16x8 fw[4][2];                  // both weight halves: fragments 0,1 = n0 ; 2,3 = n1
-
-    auto read_a = [&](const unsigned char* A, int h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rr = wrow_m + h * 64 + j * 16 + fr;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[j][ks] = *(const bf16x8*)(A + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
-        }
-    };
-    auto read_w = [&](const unsigned char* W, int h) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rr = wrow_n + h * 32 + i * 16 + fr;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fw[h * 2 + i][ks] = *(const bf16x8*)(W + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
-        }
-    };
-    auto mma = [&](int mh, int nh) {                 // quadrant (mh, nh): 4 x 2 accumulators x 2 k-steps
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[nh * 2 + i][mh * 4 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nh * 2 + i][ks], fa[j][ks], acc[nh * 2 + i][mh * 4 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // end of a read segment: retire this wave's LDS reads, then the phase's first barrier
-    auto sync_reads = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        bar();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto sync_mma = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        bar();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // ---- prologue: tile 0 complete, first three half-tiles of tile 1 in flight -------------------------------------
-    dma(0, 0); dma(2, 0); dma(3, 0); dma(1, 0);
-    dma(0, 1); dma(2, 1); dma(3, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bar();
-    if (wm == 1) bar();                               // group 1 runs one barrier behind group 0
-
-    for (int t = 0; t < nk; ++t) {
-        const unsigned char* A = smem + (t & 1) * STAGE;
-        const unsigned char* W = A + A_BYTES;
-        // phase 1: (m0, n0)
-        read_a(A, 0); read_w(W, 0);
-        dma(1, t + 1);
-        sync_reads();
-        mma(0, 0);
-        sync_mma();
-        // phase 2: (m0, n1)
-        read_w(W, 1);
-        dma(0, t + 2);
-        sync_reads();
-        mma(0, 1);
-        sync_mma();
-        // phase 3: (m1, n1)
-        read_a(A, 1);
-        dma(2, t + 2);
-        sync_reads();
-        mma(1, 1);
-        sync_mma();
-        // phase 4: (m1, n0) - operands already in registers; retire the DMA stream down to 3 half-tiles
-        dma(3, t + 2);
-        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sync_reads();
-        mma(1, 0);
-        sync_mma();
-    }
-    if (wm == 0) bar();                               // group 0 waits for group 1's last phase
-    finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
-}
-
 // ---------------------------------------------------------------------------------------------
-// Persistent form of the 8-phase kernel (round 2).  One workgroup per CU walks its tiles; what changes against
-// gemm_8phase_kernel:
+// Persistent form of the 8-phase schedule (round 2).  One workgroup per CU walks its tiles; what changes against
+// a one-tile-per-workgroup kernel:
 //   * the LDS-DMA stream never drains between tiles: during the last two K tiles of a tile the restage slots load the FIRST two
 //     K tiles of the workgroup's next tile, so the pipeline fill (one HBM/L2 round trip per tile) and the first waits are hidden
 //     behind the epilogue, and the epilogue's stores drain in the shadow of the next main loop instead of in a burst;
@@ -1190,7 +1040,7 @@ typedef __attribute__((address_space(3))) void* lds_void_t;
 // rounds x rows.  A-operand DMA slots that a smaller tile does not need are issued with an out-of-range offset (the buffer
 // range check turns them into no-ops) so that every wave keeps issuing the same number of DMA instructions per phase, which
 // is what the counted vmcnt relies on.
-template <int MF0, int MF1, bool F32OUT>
+template <int MF0, int MF1, bool F32OUT, int DIAG = 0 /* tools/gemm_lab.hip only: per-segment cycle sums into g.partial */>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     constexpr int MF = MF0 + MF1, NF = 4;
     constexpr int RG = MF * 16, BM = 2 * RG;                   // rows per wave group / per tile
@@ -1345,6 +1195,20 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // DIAG build: cycle sums per segment of a phase (s_memtime stamps; a stamp is consumed one natural lgkmcnt(0) later, so
+    // that reading it never adds a wait).  [0] read + DMA issue, [1] lgkmcnt wait of phases 1-3, [2] lgkmcnt + vmcnt wait of
+    // phase 4, [3] first barrier, [4] MFMA segment, [5] second barrier, [6] epilogue, [7] phases
+    uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds0 = 0, ds1 = 0, dp1 = 0, dp2 = 0, dp3 = 0, dp4 = 0, dp_is4 = 0;
+    auto stamp = [&]() __attribute__((always_inline)) -> uint32_t { return (uint32_t)__builtin_amdgcn_s_memtime(); };
+    auto dg_flush = [&]() __attribute__((always_inline)) {      // right after a natural lgkmcnt(0): every older stamp has landed
+        if constexpr (DIAG) {
+            if (dg[7]) {
+                if (dp_is4) dg[2] += dp2 - dp1; else dg[1] += dp2 - dp1;
+                dg[3] += dp3 - dp2; dg[4] += dp4 - dp3; dg[5] += ds0 - dp4;
+            }
+            dg[0] += ds1 - ds0; dg[7] += 1; dp1 = ds1;
+        }
+    };
     __syncthreads();                                           // bias image complete (no DMA in flight yet: a plain barrier)
     // ---- prologue of the first tile: K tile 0 complete, first three half-tiles of K tile 1 in flight (nk >= 2) ----------
     issue_cur(0, 0, 0); issue_cur(2, 0, 0); issue_cur(3, 0, 0); issue_cur(1, 0, 0);
@@ -1359,30 +1223,56 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         constexpr int TAIL = decltype(tail_c)::value;
         const unsigned char* A = smem + (gk & 1) * STAGE;
         const unsigned char* W = A + A_BYTES;
+        auto seg_reads = [&](int is4) __attribute__((always_inline)) {     // end of a read segment (DIAG: stamped)
+            if constexpr (DIAG) {
+                if (!is4) ds1 = stamp();                          // phase 4 stamps in front of its vmcnt wait
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                dg_flush(); dp_is4 = is4;
+                dp2 = stamp();
+                __builtin_amdgcn_sched_barrier(0);
+                bar();
+                __builtin_amdgcn_sched_barrier(0);
+                dp3 = stamp();
+            } else sync_reads();
+        };
+        auto seg_mma = [&]() __attribute__((always_inline)) {
+            if constexpr (DIAG) {
+                __builtin_amdgcn_sched_barrier(0);
+                dp4 = stamp();
+                bar();
+                __builtin_amdgcn_sched_barrier(0);
+                ds0 = stamp();
+            } else sync_mma();
+        };
         read_a(A, 0); read_w(W, 0);
         if constexpr (TAIL == 2) issue_nxt(1, 0, gk + 1); else issue_cur(1, t + 1, gk + 1);
-        sync_reads();
+        seg_reads(0);
         mma(0, 0);
-        sync_mma();
+        seg_mma();
         read_w(W, 1);
         if constexpr (TAIL == 0) issue_cur(0, t + 2, gk); else issue_nxt(0, TAIL - 1, gk);
-        sync_reads();
+        seg_reads(0);
         mma(0, 1);
-        sync_mma();
+        seg_mma();
         read_a(A, 1);
         if constexpr (TAIL == 0) issue_cur(2, t + 2, gk); else issue_nxt(2, TAIL - 1, gk);
-        sync_reads();
+        seg_reads(0);
         mma(1, 1);
-        sync_mma();
+        seg_mma();
         if constexpr (TAIL == 0) issue_cur(3, t + 2, gk); else issue_nxt(3, TAIL - 1, gk);
+        if constexpr (DIAG) ds1 = stamp();
         if (TAIL == 0 || has_next) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // three half-tiles stay in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sync_reads();
+        seg_reads(1);
         mma(1, 0);
-        sync_mma();
+        seg_mma();
         ++gk;
     };
 
+    uint32_t de0_ = 0;
+    const uint32_t dk0 = DIAG ? stamp() : 0;
+    if constexpr (DIAG) ds0 = dk0;
     for (;;) {
 #pragma unroll
         for (int i = 0; i < NF; ++i)
@@ -1393,6 +1283,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         ktile(nk - 1, std::integral_constant<int, 2>{});
         // ---- epilogue: 16 rows at a time through this wave's slab; no workgroup barrier (the groups stay one barrier apart) ----
         {
+            if constexpr (DIAG) de0_ = stamp();
             unsigned char* slab = smem + SLAB0 + wave * SLAB;
             const float* bl = (const float*)(smem + BIAS0) + n0 + wrow_n + fq * 4;
             if constexpr (!F32OUT) {
@@ -1484,6 +1375,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                 }
             }
         }
+        if constexpr (DIAG) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint32_t de1 = stamp();
+            dg[6] += de1 - de0_; ds0 = de1;
+        }
         if (!has_next) break;
         seq += Lx;
         m0 = m0n; n0 = n0n;
@@ -1493,6 +1389,15 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         if (has_next) { coords(seq + Lx, m0n, n0n); set_offsets(onxt, m0n, n0n); }
     }
     if (wm == 0) bar();                                        // group 0 waits for group 1's last barrier
+    if constexpr (DIAG) {
+        const uint32_t dk1 = stamp();
+        if (lane == 0) {
+            uint32_t* o = (uint32_t*)g.partial + ((long long)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = dg[i];
+            o[8] = dk1 - dk0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1564,14 +1469,381 @@ int launch_p8(GemmArgs& g, hipStream_t st) {
     }
 }
 
-int launch_8phase(GemmArgs& g, hipStream_t st) {
-    g.tiles_m = (g.M + 255) / 256;
-    g.tiles_n = (g.N + 255) / 256;
-    const size_t lds = 2 * (size_t)(256 + 256) * 128;
-    if (hipFuncSetAttribute((const void*)gemm_8phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+// ---------------------------------------------------------------------------------------------
+// gemm_p9_kernel (round 3): the persistent tile walk, LDS map and LDS-DMA addressing of gemm_p8_kernel with a FREE-RUNNING main
+// loop.  What the per-segment stamps of the DIAG build showed for gemm_p8_kernel (tools/gemm_lab.hip): a phase costs
+// ~890 cycles where its two MFMA segments need 512; the read segment is not LDS latency but the ISSUE of the two LDS-DMA
+// instructions (~85 cycles each while the four waves of a group issue theirs at once; the waits on landing DMA are ~25 cycles
+// per K tile), and each of the 8 barriers of a K tile costs the last arriver ~65 cycles.  So here:
+//   * ONE barrier per K tile instead of eight.  A wave's program for a K tile is P = ceil(MF / 2) phases of 16 MFMAs (two row
+//     fragments x four column fragments x two 32-deep steps); the fragment reads of phase p+1 are issued at the top of phase p into
+//     the other half of a two-deep register ring (16 registers each), the weight fragments of K tile t+1 replace those of K tile t
+//     in place inside the last phase (after their last use), so LDS latency is covered by the wave's OWN MFMAs and the two waves of
+//     a SIMD are not forced to alternate: whichever has operands issues, and the waves of a workgroup drift apart instead of
+//     bursting on the LDS-DMA path together;
+//   * the sync point S (end of phase P-2: vmcnt(0) + lgkmcnt(0) + barrier) retires K tile t+1 and frees the whole stage of K tile
+//     t at once (its last fragment reads were issued one phase earlier); the 8 DMA instructions per wave and K tile are spread over
+//     the phases that follow S (activation pieces first: they can miss L2; weight pieces last: they never do; none in the phase
+//     that ends in the next S);
+//   * LDS-free epilogue.  bf16 outputs: the weight rows of a wave's 64 columns are PERMUTED on the DMA source side so that MFMA
+//     fragment i, row r holds column (r >> 2) * 16 + i * 4 + (r & 3): a lane's 16 accumulator values of one output row are 16
+//     consecutive columns = two 16-byte stores straight from registers (64-byte row segments per wave-instruction).  f32 outputs
+//     keep the plain order (a lane's four values per fragment are 16 bytes, a fragment's 16 columns one 64-byte segment).  The
+//     slabs, their lgkmcnt round trips (5.5 k cycles per 256 x 256 tile) and 16 KB of LDS are gone.
+// Instances: MF (16-row fragments per wave group; tile = 32 MF rows x 256 columns) in 5..8; K / 64 >= 2, even when P is odd.
+// ---------------------------------------------------------------------------------------------
+template <int V> using ic = std::integral_constant<int, V>;
+
+template <int MF, bool F32OUT>
+__global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
+    constexpr int NF = 4, P = (MF + 1) / 2;
+    constexpr int MF0 = (MF + 1) / 2, MF1 = MF - MF0;          // DMA halves of the activation rows of a group (piece bookkeeping of p8)
+    constexpr int RG = MF * 16, BM = 2 * RG;
+    constexpr int A_BYTES = 256 * 128, STAGE = 2 * A_BYTES, BIAS0 = 2 * STAGE;
+    constexpr bool PERM = !F32OUT;
+    static_assert(MF >= 5 && MF <= 8, "tile heights 160..256");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int M = g.M;
+    if (g.m_dev) { long long md = (long long)g.m_dev[0] * g.m_mul; M = md < M ? (int)md : M; }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = g.N >> 8;
+    const int ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    int Lx, seq0, seq1, lid;
+    if (g.sched == 1) {
+        const int nx = G < 8 ? G : 8;
+        const int xcd = (int)blockIdx.x % nx;
+        lid = (int)blockIdx.x / nx;
+        Lx = (G - xcd + nx - 1) / nx;
+        int cum = 0;
+        for (int y = 0; y < xcd; ++y) cum += (G - y + nx - 1) / nx;
+        seq0 = (int)((long long)ntiles * cum / G); seq1 = (int)((long long)ntiles * (cum + Lx) / G);
+    } else {
+        const int q = G >> 3, r = G & 7, x = blockIdx.x & 7;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);
+        Lx = G; seq0 = 0; seq1 = ntiles;
+    }
+    if (seq0 + lid >= seq1) return;
+    {
+        float* bl = (float*)(smem + BIAS0);
+        for (int i = tid; i < g.N; i += 512) bl[i] = (g.flags & YV_EPI_BIAS) ? g.bias[i] : 0.0f;
+    }
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.a0, 0, (int)(((long long)(g.M - 1) * g.lda0 + g.K) * 2), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (int)((long long)g.N * g.K * 2), 0x00020000);
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)(((long long)(M - 1) * g.ldo + g.N) * (F32OUT ? 4 : 2)), 0x00020000);
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wrow_m = wm * RG, wrow_n = wn * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int lrow = lane >> 3, lch = lane & 7;
+    auto coords = [&](int seq, int& m0, int& n0) __attribute__((always_inline)) {
+        const int GM = g.group_m, per = GM * tiles_n;
+        const int grp = seq / per, first = grp * GM;
+        const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
+        const int in = seq - grp * per;
+        m0 = (first + in % gsz) * BM;
+        n0 = (in / gsz) << 8;
+    };
+    auto a_piece_row = [&](int h, int s) __attribute__((always_inline)) -> int {
+        const int len8 = (h == 0 ? MF0 : MF1) * 2;
+        if (s >= 2 * len8) return -1;
+        const int grp = s / len8, r8 = s - grp * len8;
+        return grp * RG + (h == 0 ? 0 : MF0 * 16) + r8 * 8;
+    };
+    // DMA source offsets.  Activation pieces: per-lane byte offset of (tile row, swizzled chunk) - ONE set, pointed at the next
+    // tile from K tile nk-2 on (the current tile's last activation pieces are issued in K tile nk-3); rows past M get an
+    // out-of-range offset (the range check returns zeros).  Weight pieces: a lane part that never changes + the tile's n0 * K
+    // in the instruction's scalar offset.
+    auto set_a_offsets = [&](uint32_t (&o)[2][2], int m0, bool valid) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int s_ = wave * 2 + j;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r0 = a_piece_row(h, s_);
+                const int ra = r0 + lrow, m = m0 + ra;
+                o[h][j] = (valid && r0 >= 0 && m < g.M) ? (uint32_t)(((long long)m * g.lda0 + ((lch ^ (ra & 7)) << 3)) * 2) : 0x80000000u;
+            }
+        }
+    };
+    uint32_t ow[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rh = (wave * 2 + j) * 8 + lrow;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rw = (rh >> 5) * 64 + h * 32 + (rh & 31);          // LDS row of the W tile
+            // PERM: LDS row (block b, fragment i, row r) holds weight row b * 64 + (r >> 2) * 16 + i * 4 + (r & 3)
+            const int rsrc = PERM ? ((rw & ~63) | (((rw & 15) >> 2) << 4) | (((rw >> 4) & 3) << 2) | (rw & 3)) : rw;
+            ow[h][j] = (uint32_t)((rsrc * g.K + ((lch ^ (rw & 7)) << 3)) * 2);
+        }
+    }
+    auto lds_dst = [&](int kind, int j) __attribute__((always_inline)) -> int {
+        const int s_ = wave * 2 + j;
+        if (kind < 2) {
+            const int r0 = a_piece_row(kind, s_);
+            return (r0 >= 0 ? r0 : BM) * 128;
+        }
+        const int rb = s_ * 8;
+        return A_BYTES + ((rb >> 5) * 64 + (kind - 2) * 32 + (rb & 31)) * 128;
+    };
+
+    const int nk = g.K / BK;
+    uint32_t oa[2][2];
+    int seq = seq0 + lid, m0, n0, m0n = 0, n0n = 0;
+    coords(seq, m0, n0);
+    set_a_offsets(oa, m0, true);
+    bool has_next = seq + Lx < seq1;
+    if (has_next) coords(seq + Lx, m0n, n0n);
+    int gk = 0;                                                // K tiles consumed so far (stage of a K tile = parity)
+
+    // piece `kind` (0, 1 activation halves; 2, 3 weight halves) of K tile k of the tile whose column origin is nb
+    auto issue_a = [&](int kind, int k, int st) __attribute__((always_inline)) {
+        unsigned char* base = smem + (st & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t)(base + lds_dst(kind, j)), 16, (int)oa[kind][j], k * 128, 0, 0);
+    };
+    auto issue_w = [&](int kind, int k, int st, int nb) __attribute__((always_inline)) {
+        unsigned char* base = smem + (st & 1) * STAGE;
+        const int so = nb * g.K * 2 + k * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t)(base + lds_dst(kind, j)), 16, (int)ow[kind - 2][j], so, 0, 0);
+    };
+    // K tile t + d (d in {1, 2}) of this tile or, past its end, of the next tile
+    auto issue_rel = [&](int kind, int t, int d, auto tail_c) __attribute__((always_inline)) {
+        constexpr int TAIL = decltype(tail_c)::value;             // 0: t <= nk-3, 1: t = nk-2, 2: t = nk-1
+        const int st = gk + d;
+        if (kind < 2) issue_a(kind, TAIL + d <= 2 ? t + d : TAIL + d - 3, st);       // `oa` already points at the right tile
+        else if (TAIL + d <= 2) issue_w(kind, t + d, st, n0);
+        else if (has_next) issue_w(kind, TAIL + d - 3, st, n0n);
+    };
+
+    f32x4 acc[NF][MF];
+    bf16x8 fa[2][2][2];                                         // [ring half][row fragment of the pair][k step]
+    bf16x8 fw[4][2];                                            // [column fragment][k step] of the current K tile
+    auto read_pair = [&](auto half_c, const unsigned char* A, int pr) __attribute__((always_inline)) {
+        constexpr int HALF = decltype(half_c)::value;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if (2 * pr + jj >= MF) continue;
+            const int rr = wrow_m + (2 * pr + jj) * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[HALF][jj][ks] = *(const bf16x8*)(A + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+        }
+    };
+    auto read_w = [&](const unsigned char* W, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = wrow_n + i * 16 + fr;
+            fw[i][ks] = *(const bf16x8*)(W + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+        }
+    };
+    auto mma = [&](auto half_c, int pr, int ks) __attribute__((always_inline)) {
+        constexpr int HALF = decltype(half_c)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                if (2 * pr + jj >= MF) continue;
+                acc[i][2 * pr + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][ks], fa[HALF][jj][ks], acc[i][2 * pr + jj], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // DMA pieces of the window that follows a sync point: phase P-1 (of the K tile of the sync point) takes both activation halves
+    // of K tile t+2, the first phases of the next K tile the weight halves of (its) K tile t+1; phase P-2 - the one that ends in
+    // the next sync point - issues nothing, so the youngest piece has a whole phase to land before it is waited for
+    auto dma_for_phase = [&](int p, int t, auto tail_c) __attribute__((always_inline)) {
+        if (p == P - 1) { issue_rel(0, t, 2, tail_c); issue_rel(1, t, 2, tail_c); return; }
+        if constexpr (P == 4) { if (p < 2) issue_rel(2 + p, t, 1, tail_c); }
+        else { if (p == 0) { issue_rel(2, t, 1, tail_c); issue_rel(3, t, 1, tail_c); } }
+    };
+    // one K tile.  PAR: ring half that holds row pair 0 of this K tile (odd P: alternates).  LASTK: t = nk - 1
+    auto ktile = [&](int t, auto tail_c, auto par_c) __attribute__((always_inline)) {
+        constexpr int TAIL = decltype(tail_c)::value, PAR = decltype(par_c)::value;
+        if constexpr (TAIL == 1) set_a_offsets(oa, m0n, has_next);                 // from here on activation pieces belong to the next tile
+        const unsigned char* A = smem + (gk & 1) * STAGE;
+        const unsigned char* An = smem + ((gk + 1) & 1) * STAGE;
+        auto phase = [&](auto p_c) __attribute__((always_inline)) {
+            constexpr int p = decltype(p_c)::value;
+            constexpr int CUR = (PAR + p) & 1, NXT = CUR ^ 1;
+            if constexpr (p + 1 < P) read_pair(ic<NXT>{}, A, p + 1);
+            else if constexpr (TAIL != 2) read_pair(ic<NXT>{}, An, 0);          // row pair 0 of the next K tile
+            dma_for_phase(p, t, tail_c);
+            mma(ic<CUR>{}, p, 0);
+            if constexpr (p == P - 1 && TAIL != 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_w(An + A_BYTES, 0);                                        // in place: k step 0 of K tile t had its last use
+            }
+            mma(ic<CUR>{}, p, 1);
+            if constexpr (p == P - 1 && TAIL != 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_w(An + A_BYTES, 1);
+            }
+            if constexpr (p == P - 2) {
+                // sync point: every DMA issued so far (all of K tile t+1) has landed, this wave's fragment reads are retired;
+                // behind the barrier K tile t+1 is visible to every wave and the stage of K tile t is free
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                bar();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        phase(ic<0>{});
+        if constexpr (P > 1) phase(ic<1>{});
+        if constexpr (P > 2) phase(ic<2>{});
+        if constexpr (P > 3) phase(ic<3>{});
+        ++gk;
+    };
+
+    __syncthreads();                                           // bias image complete (no DMA in flight yet)
+    // ---- first tile: K tile 0 complete, the activation halves of K tile 1 in flight ---------------------------------------
+    issue_a(0, 0, 0); issue_a(1, 0, 0); issue_w(2, 0, 0, n0); issue_w(3, 0, 0, n0);
+    issue_a(0, 1, 1); issue_a(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    bar();
+
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {   // tile prologue: weight fragments and row pair 0 of K tile 0 (landed and visible since the previous sync point)
+            const unsigned char* A = smem + (gk & 1) * STAGE;
+            read_w(A + A_BYTES, 0); read_w(A + A_BYTES, 1);
+            read_pair(ic<0>{}, A, 0);
+        }
+        if constexpr (P & 1) {
+            for (int t = 0; t < nk - 2; t += 2) { ktile(t, ic<0>{}, ic<0>{}); ktile(t + 1, ic<0>{}, ic<1>{}); }
+            ktile(nk - 2, ic<1>{}, ic<0>{});
+            ktile(nk - 1, ic<2>{}, ic<1>{});
+        } else {
+            for (int t = 0; t < nk - 2; ++t) ktile(t, ic<0>{}, ic<0>{});
+            ktile(nk - 2, ic<1>{}, ic<0>{});
+            ktile(nk - 1, ic<2>{}, ic<0>{});
+        }
+        // ---- epilogue: straight from the accumulators ------------------------------------------------------------------------
+        if constexpr (!F32OUT) {
+            const bool gelu = g.flags & YV_EPI_GELU;
+            const float* bl = (const float*)(smem + BIAS0) + n0 + wrow_n + fq * 16;
+            float4 bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = *(const float4*)(bl + i * 4);
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = m0 + wrow_m + j * 16 + fr;
+                uint32_t pk[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
+                    float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                    if (gelu) { v0 = gelu_f(v0); v1 = gelu_f(v1); v2 = gelu_f(v2); v3 = gelu_f(v3); }
+                    pk[2 * i] = pack_bf16x2(v0, v1); pk[2 * i + 1] = pack_bf16x2(v2, v3);
+                }
+                const uint32_t off = m < M ? (uint32_t)((m * g.ldo + n0 + wrow_n + fq * 16) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[0], pk[1], pk[2], pk[3]}, rsO, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[4], pk[5], pk[6], pk[7]}, rsO, off, 16, 0);
+            }
+        } else {
+            const bool rmw = g.flags & YV_EPI_RES_F32;
+            const float* bl = (const float*)(smem + BIAS0) + n0 + wrow_n + fq * 4;
+            float4 bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = *(const float4*)(bl + i * 16);
+            constexpr int JA = 2;                                // row fragments whose residual values are in flight together
+#pragma unroll
+            for (int j0 = 0; j0 < MF; j0 += JA) {
+                u32x4 xr[JA][4];
+                uint32_t off[JA];
+#pragma unroll
+                for (int jj = 0; jj < JA; ++jj) {
+                    const int m = m0 + wrow_m + (j0 + jj) * 16 + fr;
+                    off[jj] = (j0 + jj < MF && m < M) ? (uint32_t)((m * g.ldo + n0 + wrow_n + fq * 4) * 4) : 0x80000000u;
+                    if (rmw) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xr[jj][i] = __builtin_amdgcn_raw_buffer_load_b128(rsO, off[jj], i * 64, 0);
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < JA; ++jj) {
+                    if (j0 + jj >= MF) continue;
+                    const int j = j0 + jj;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
+                        float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                        if (rmw) {
+                            v0 += __uint_as_float(xr[jj][i][0]); v1 += __uint_as_float(xr[jj][i][1]);
+                            v2 += __uint_as_float(xr[jj][i][2]); v3 += __uint_as_float(xr[jj][i][3]);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2),
+                                                                       __float_as_uint(v3)}, rsO, off[jj], i * 64, 0);
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        seq += Lx;
+        m0 = m0n; n0 = n0n;
+        has_next = seq + Lx < seq1;
+        if (has_next) coords(seq + Lx, m0n, n0n);
+    }
+}
+
+template <int MF, bool F32OUT>
+int launch_p9_inst(GemmArgs& g, hipStream_t st, int n_cu) {
+    constexpr int BM = 32 * MF;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = g.N / 256;
+    const size_t lds = 2 * 65536 + 16384;
+    auto kern = gemm_p9_kernel<MF, F32OUT>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return YV_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_8phase_kernel, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int grid = tiles < n_cu ? tiles : n_cu;
+    if (t_time_start || t_time_stop) {
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), (uint32_t)lds, st, t_time_start, t_time_stop, 0, g);
+        t_time_start = t_time_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g);
+    }
     return yv_launch_status();
+}
+
+// rows: 0 = choose (minimise rounds x (rows + per-tile cost)), else 160 / 192 / 224 / 256
+int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0) {
+    static int n_cu_dev = 0;
+    if (!n_cu_dev) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return YV_ERR_LAUNCH;
+        n_cu_dev = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int n_cu = (g_opt_p8_cus > 0 && g_opt_p8_cus < n_cu_dev) ? g_opt_p8_cus : n_cu_dev;
+    g.sched = g_opt_p8_sched;
+    const bool f32out = g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32);
+    const bool even_nk = ((g.K / BK) & 1) == 0;                    // odd-P instances (160 / 192 rows) walk K tiles in pairs
+    int best = rows ? rows : g_opt_p8_rows;
+    if (!best) {
+        long long best_cost = -1;
+        const int cand[4] = {256, 224, 192, 160};
+        for (int c = 0; c < 4; ++c) {
+            if (cand[c] <= 192 && !even_nk) continue;
+            const long long tiles = (long long)((g.M + cand[c] - 1) / cand[c]) * (g.N / 256);
+            const long long rounds = (tiles + n_cu - 1) / n_cu;
+            const long long cost = rounds * (cand[c] + 16);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand[c]; }
+        }
+    }
+    if (best <= 192 && !even_nk) best = 224;
+    switch (best) {
+        case 224: return f32out ? launch_p9_inst<7, true>(g, st, n_cu) : launch_p9_inst<7, false>(g, st, n_cu);
+        case 192: return f32out ? launch_p9_inst<6, true>(g, st, n_cu) : launch_p9_inst<6, false>(g, st, n_cu);
+        case 160: return f32out ? launch_p9_inst<5, true>(g, st, n_cu) : launch_p9_inst<5, false>(g, st, n_cu);
+        default: return f32out ? launch_p9_inst<8, true>(g, st, n_cu) : launch_p9_inst<8, false>(g, st, n_cu);
+    }
 }
 
 
@@ -1857,8 +2129,6 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!strcmp(key, "linear_p8_sched")) { g_opt_p8_sched = value; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_splitk")) { g_opt_linear_splitk = value; return YV_OK; }
-    if (!strcmp(key, "linear_wide_min_n")) { g_opt_wide_min = value; return YV_OK; }
-    if (!strcmp(key, "linear_wide_max_n")) { g_opt_wide_max = value; return YV_OK; }
     return YV_ERR_ARG;
 }
 
@@ -1902,7 +2172,6 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
         // auto: 128x128 tiles, two workgroups per CU (one workgroup's epilogue overlaps the other's main loop).
         // Isolated, the 8-phase 256x256 kernel is 3-13 % faster on N >= 1536, but inside the pipeline (operands
         // cold in L2, GELU / residual epilogues) the interleaved end-to-end A/B measures it 1-2 % slower.
-        if (variant == 1 && N >= g_opt_wide_min && N <= g_opt_wide_max && M >= 2048) variant = 8;   // 8-phase 256x256
         // persistent 8-phase kernel: wide bf16-output linears (the qkv / fc1 shapes), see gemm_p8_kernel for its restrictions
         const bool p8_ok = !(N & 255) && N <= 4096 && K >= 128 &&
                            !(flags & ~(YV_EPI_BIAS | YV_EPI_GELU | YV_EPI_RES_F32 | YV_EPI_OUT_F32)) &&
@@ -1915,7 +2184,6 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
             case 2: return launch_dma<256, 128, 4, 2>(g, stream);
             case 3: return launch_dma<256, 256, 2, 4>(g, stream);
             case 4: return launch_dma<128, 256, 2, 4>(g, stream);
-            case 8: return launch_8phase(g, stream);
             case 9: return launch_p8(g, stream);
             case 201: return launch_dma<256, 256, 2, 4, 1>(g, stream);
             case 202: return launch_dma<256, 256, 2, 4, 2>(g, stream);

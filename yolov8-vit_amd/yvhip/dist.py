@@ -47,8 +47,12 @@ class BucketReducer:
     bucket that lies entirely at or above offset `low`; `finish()` waits for all of them.  Buckets are
     fixed slices counted from the end, so every rank issues the same collectives in the same order."""
 
-    def __init__(self, flat: torch.Tensor, bucket_elems: int):
+    def __init__(self, flat: torch.Tensor, bucket_elems: int, force: bool = False):
+        """force (or YV_DP_FORCE_COLLECTIVE=1): issue the collectives even in a one-rank group - a one-GPU box can then
+        exercise the real transport (RCCL communicator set-up, the async all-reduce on the wgrad side stream, the handle
+        waits against the trainer's two streams); a SUM over one rank leaves the gradients bit for bit unchanged."""
         self.flat, self.bucket = flat, max(int(bucket_elems), 1)
+        self.force = bool(force) or os.environ.get("YV_DP_FORCE_COLLECTIVE", "0") == "1"
         self.reset()
 
     def reset(self):
@@ -58,7 +62,7 @@ class BucketReducer:
 
     def ready(self, low: int):
         import torch.distributed as dist
-        active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force)
         while self.next_hi > 0:
             lo = max(self.next_hi - self.bucket, 0)
             if lo < low:
