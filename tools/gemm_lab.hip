@@ -62,13 +62,32 @@ static float time_us(const Problem& p, const Launcher& fn, int iters) {
     return ms * 1000.0f / iters;
 }
 
-static size_t mismatches(const Problem& p) {          // p.out vs p.ref, bytewise on host
+static size_t mismatches(const Problem& p, bool verbose = false) {          // p.out vs p.ref, bytewise on host
     std::vector<unsigned char> a(p.out_bytes), b(p.out_bytes);
     CK(hipMemcpy(a.data(), p.out, p.out_bytes, hipMemcpyDeviceToHost));
     CK(hipMemcpy(b.data(), p.ref, p.out_bytes, hipMemcpyDeviceToHost));
-    const size_t es = (p.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32)) ? 4 : 2;
-    size_t bad = 0;
-    for (size_t i = 0; i < p.out_bytes; i += es) bad += memcmp(&a[i], &b[i], es) != 0;
+    const bool f32 = p.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32);
+    const size_t es = f32 ? 4 : 2;
+    size_t bad = 0; double maxd = 0; int shown = 0;
+    std::vector<size_t> rowhist(256, 0), colhist(256, 0);
+    for (size_t i = 0; i < p.out_bytes; i += es) {
+        if (memcmp(&a[i], &b[i], es) == 0) continue;
+        ++bad;
+        const size_t e = i / es, r = e / p.N, c = e % p.N;
+        rowhist[r & 255]++; colhist[c & 255]++;
+        if (f32) {
+            float x, y; memcpy(&x, &a[i], 4); memcpy(&y, &b[i], 4);
+            maxd = std::max(maxd, (double)fabsf(x - y));
+            if (verbose && shown < 6) { printf("     (%zu, %zu): got %.9g ref %.9g\n", r, c, x, y); ++shown; }
+        }
+    }
+    if (bad && verbose) {
+        printf("     max abs diff %.3g; mismatches by row %% 256 (16-row bins):", maxd);
+        for (int k = 0; k < 16; ++k) { size_t s_ = 0; for (int q = 0; q < 16; ++q) s_ += rowhist[k * 16 + q]; printf(" %zu", s_); }
+        printf("\n     by col %% 256 (16-col bins):");
+        for (int k = 0; k < 16; ++k) { size_t s_ = 0; for (int q = 0; q < 16; ++q) s_ += colhist[k * 16 + q]; printf(" %zu", s_); }
+        printf("\n");
+    }
     return bad;
 }
 
@@ -120,6 +139,38 @@ static void run_diag(const Problem& p, int n_cu) {
     CK(hipFree(dbg));
 }
 
+template <int MF, bool F32OUT>
+static void run_diag9(const Problem& p, int n_cu) {
+    GemmArgs g = args_of(p, p.out);
+    uint32_t* dbg; const size_t n = (size_t)n_cu * 8 * 16;
+    CK(hipMalloc(&dbg, n * 4)); CK(hipMemset(dbg, 0, n * 4));
+    g.partial = (float*)dbg; g.sched = g_opt_p8_sched;
+    constexpr int BM = 32 * MF;
+    g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = g.N / 256;
+    const size_t lds = 2 * 65536 + 16384;
+    auto kern = gemm_p9_kernel<MF, F32OUT, 1>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tiles = g.tiles_m * g.tiles_n, grid = tiles < n_cu ? tiles : n_cu;
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<uint32_t> h(n);
+    CK(hipMemcpy(h.data(), dbg, n * 4, hipMemcpyDeviceToHost));
+    double s[8] = {0}; int cnt = 0;
+    for (int b = 0; b < grid; ++b)
+        for (int w = 0; w < 8; ++w) {
+            const uint32_t* o = &h[((size_t)b * 8 + w) * 16];
+            if (!o[5]) continue;
+            for (int i = 0; i < 8; ++i) s[i] += o[i];
+            ++cnt;
+        }
+    if (cnt) {
+        const double tiles_w = s[5] / cnt, nk = p.K / 64;
+        printf("  diag9 %s MF %d: tiles/wave %.2f total %.0f cyc | per tile: main %.0f (%.0f per K tile; MFMA floor %d) epilogue %.0f | per sync: wait %.0f barrier %.0f | first sync of a tile: wait %.0f\n",
+               p.name, MF, tiles_w, s[7] / cnt, s[2] / s[5], s[2] / s[5] / nk, MF * 4 * 2 * 16 * 2, s[3] / s[5], s[0] / s[6], s[1] / s[6], s[4] / s[5]);
+    }
+    CK(hipFree(dbg));
+}
+
 int main(int argc, char** argv) {
     const int M = getenv("LAB_M") ? atoi(getenv("LAB_M")) : 25216;
     const int iters = 10, rounds = 5;
@@ -147,7 +198,7 @@ int main(int argc, char** argv) {
             fill_out(p, p.out);
             { GemmArgs g = args_of(p, p.out); if (vs[v].fn(g, 0) != YV_OK) { printf("launch failed\n"); return 1; } }
             CK(hipDeviceSynchronize());
-            const size_t bad = mismatches(p);
+            const size_t bad = mismatches(p, true);
             if (bad) printf("  !! %s %s: %zu of %zu outputs differ from the shipped kernel\n", p.name, vs[v].name.c_str(), bad, (size_t)p.M * p.N);
         }
         for (int r = 0; r < rounds; ++r)
@@ -166,6 +217,12 @@ int main(int argc, char** argv) {
     for (size_t v = 0; v < vs.size(); ++v)
         printf("LAYER %-24s %7.1f us  flop-weighted frac %.3f\n", vs[v].name.c_str(), tot_us[v], tot_fl / tot_us[v] / 1e6 / 2500.0);
     if (!getenv("LAB_NO_DIAG")) {
+        run_diag9<7, false>(ps[0], n_cu);
+        run_diag9<5, true>(ps[1], n_cu);
+        run_diag9<8, false>(ps[2], n_cu);
+        run_diag9<5, true>(ps[3], n_cu);
+    }
+    if (getenv("LAB_DIAG8")) {
         run_diag<4, 3, false>(ps[0], n_cu);
         run_diag<4, 4, false>(ps[0], n_cu);
         run_diag<3, 2, true>(ps[1], n_cu);

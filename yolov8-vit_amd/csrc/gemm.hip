@@ -22,6 +22,7 @@
 #include <type_traits>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include "yv_common.h"
 #include <hip/hip_ext.h>
 
@@ -33,8 +34,8 @@ thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;   // yv_s
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
 int g_opt_group_m = 8;
 int g_opt_staged = 1;
-int g_opt_p8 = 2;                  // persistent 8-phase kernel: 0 off, 1 wide bf16-output linears only (qkv, fc1), 2 every eligible
-                                   // linear incl. the f32 residual ones (proj, fc2): "linear_p8"
+int g_opt_p8 = 3;                  // persistent kernels: 0 off, 1 8-phase kernel for wide bf16-output linears only (qkv, fc1), 2 for every
+                                   // eligible linear incl. the f32 residual ones (proj, fc2), 3 the free-running kernel (gemm_p9_kernel): "linear_p8"
 std::mutex g_ws_mu;
 std::map<void*, std::pair<void*, size_t>> g_ws;   // per-stream split-K workspace (yv_set_workspace)
 static bool ws_lookup(void* stream, void** ws, size_t* bytes) {
@@ -1494,7 +1495,7 @@ int launch_p8(GemmArgs& g, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 template <int V> using ic = std::integral_constant<int, V>;
 
-template <int MF, bool F32OUT>
+template <int MF, bool F32OUT, int DIAG = 0 /* tools/gemm_lab.hip only: cycle sums into g.partial */>
 __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     constexpr int NF = 4, P = (MF + 1) / 2;
     constexpr int MF0 = (MF + 1) / 2, MF1 = MF - MF0;          // DMA halves of the activation rows of a group (piece bookkeeping of p8)
@@ -1653,6 +1654,8 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
             }
         __builtin_amdgcn_s_setprio(0);
     };
+    uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dtb = 0, dtc = 0;   // DIAG: [0] sync waits [1] barrier waits [2] main loops [3] epilogues
+    auto stamp = [&]() __attribute__((always_inline)) -> uint32_t { return (uint32_t)__builtin_amdgcn_s_memtime(); };   // [4] first sync of a tile [5] tiles [6] syncs
     // DMA pieces of the window that follows a sync point: phase P-1 (of the K tile of the sync point) takes both activation halves
     // of K tile t+2, the first phases of the next K tile the weight halves of (its) K tile t+1; phase P-2 - the one that ends in
     // the next sync point - issues nothing, so the youngest piece has a whole phase to land before it is waited for
@@ -1686,9 +1689,24 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
             if constexpr (p == P - 2) {
                 // sync point: every DMA issued so far (all of K tile t+1) has landed, this wave's fragment reads are retired;
                 // behind the barrier K tile t+1 is visible to every wave and the stage of K tile t is free
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                bar();
+                if constexpr (DIAG) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const uint32_t ta = stamp();
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dg[6]) dg[1] += dtc - dtb;                 // barrier wait of the previous sync point (stamp landed by now)
+                    const uint32_t tb = stamp();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    dg[0] += tb - ta; if (t == 0) dg[4] += tb - ta; dg[6] += 1; dtb = tb;
+                    bar();
+                    __builtin_amdgcn_sched_barrier(0);
+                    dtc = stamp();
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    bar();
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -1706,7 +1724,10 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     bar();
 
+    const uint32_t dk0 = DIAG ? stamp() : 0;
     for (;;) {
+        uint32_t dt0 = 0, dt1 = 0;
+        if constexpr (DIAG) dt0 = stamp();
 #pragma unroll
         for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -1726,6 +1747,7 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
             ktile(nk - 1, ic<2>{}, ic<0>{});
         }
         // ---- epilogue: straight from the accumulators ------------------------------------------------------------------------
+        if constexpr (DIAG) { dt1 = stamp(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dg[2] += dt1 - dt0; dg[5] += 1; }
         if constexpr (!F32OUT) {
             const bool gelu = g.flags & YV_EPI_GELU;
             const float* bl = (const float*)(smem + BIAS0) + n0 + wrow_n + fq * 16;
@@ -1764,7 +1786,7 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
                     off[jj] = (j0 + jj < MF && m < M) ? (uint32_t)((m * g.ldo + n0 + wrow_n + fq * 4) * 4) : 0x80000000u;
                     if (rmw) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) xr[jj][i] = __builtin_amdgcn_raw_buffer_load_b128(rsO, off[jj], i * 64, 0);
+                        for (int i = 0; i < 4; ++i) xr[jj][i] = __builtin_amdgcn_raw_buffer_load_b128(rsO, off[jj] + i * 64, 0, 0);
                     }
                 }
 #pragma unroll
@@ -1779,17 +1801,32 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
                             v0 += __uint_as_float(xr[jj][i][0]); v1 += __uint_as_float(xr[jj][i][1]);
                             v2 += __uint_as_float(xr[jj][i][2]); v3 += __uint_as_float(xr[jj][i][3]);
                         }
+                        // the column step goes into the instruction's immediate offset, never into an SGPR soffset: behind a 16-byte
+                        // store with a REGISTER soffset hipcc pads nothing before the next write of the data registers (LLVM takes that
+                        // form to be free of the store-data hazard) and on gfx950 the store then read overwritten values (measured:
+                        // 0.9 % of the outputs wrong, always the columns whose step needed a register: 128 and 192 bytes)
                         __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2),
-                                                                       __float_as_uint(v3)}, rsO, off[jj], i * 64, 0);
+                                                                       __float_as_uint(v3)}, rsO, off[jj] + i * 64, 0, 0);
                     }
                 }
             }
         }
+        if constexpr (DIAG) { const uint32_t dt2 = stamp(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dg[3] += dt2 - dt1; }
         if (!has_next) break;
         seq += Lx;
         m0 = m0n; n0 = n0n;
         has_next = seq + Lx < seq1;
         if (has_next) coords(seq + Lx, m0n, n0n);
+    }
+    if constexpr (DIAG) {
+        const uint32_t dk1 = stamp();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dg[7] = dk1 - dk0;
+        if (lane == 0) {
+            uint32_t* o = (uint32_t*)g.partial + ((long long)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = dg[i];
+        }
     }
 }
 
@@ -1800,8 +1837,16 @@ int launch_p9_inst(GemmArgs& g, hipStream_t st, int n_cu) {
     g.tiles_n = g.N / 256;
     const size_t lds = 2 * 65536 + 16384;
     auto kern = gemm_p9_kernel<MF, F32OUT>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return YV_ERR_LAUNCH;
+    {   // the dynamic-LDS grant belongs to the device's copy of the kernel: once per device and instance
+        static std::atomic<unsigned> granted[2] = {{0u}, {0u}};    // bit d: device d (up to 64 devices)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return YV_ERR_LAUNCH;
+        if (!((granted[dev >> 5].load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return YV_ERR_LAUNCH;
+            granted[dev >> 5].fetch_or(1u << (dev & 31), std::memory_order_release);
+        }
+    }
     const int tiles = g.tiles_m * g.tiles_n;
     const int grid = tiles < n_cu ? tiles : n_cu;
     if (t_time_start || t_time_stop) {
@@ -1831,6 +1876,7 @@ int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0) {
         const int cand[4] = {256, 224, 192, 160};
         for (int c = 0; c < 4; ++c) {
             if (cand[c] <= 192 && !even_nk) continue;
+            if (cand[c] > 192 && f32out && even_nk) continue;      // f32 outputs: the residual prefetch next to the accumulators spills above 192 rows
             const long long tiles = (long long)((g.M + cand[c] - 1) / cand[c]) * (g.N / 256);
             const long long rounds = (tiles + n_cu - 1) / n_cu;
             const long long cost = rounds * (cand[c] + 16);
@@ -2178,13 +2224,17 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
                            !((flags & YV_EPI_GELU) && (flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32))) && g.staged && !res_f32 && !aux &&
                            ((long long)(M - 1) * lda + K) * 2 < 0x7fffffffLL && (long long)N * K * 2 < 0x7fffffffLL &&
                            ((long long)(M - 1) * ldo + N) * 4 < 0x7fffffffLL && !(ldo & 7) && !(lda & 7);
-        if (variant == 1 && g_opt_p8 && p8_ok && M >= 2048 && (N >= 1536 || g_opt_p8 >= 2)) variant = 9;
-        if (variant == 9 && !p8_ok) variant = 1;
+        if (variant == 1 && g_opt_p8 && p8_ok && M >= 2048 && (N >= 1536 || g_opt_p8 >= 2)) variant = g_opt_p8 >= 3 ? 11 : 9;
+        if ((variant == 9 || variant == 11) && !p8_ok) variant = 1;
+        // free-running form (round 3): f32 outputs have the registers for 160-row tiles only, whose three-phase K tiles are walked
+        // in pairs (K / 64 even); the 8-phase kernel takes the rest
+        if (variant == 11 && (flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32)) && ((K / BK) & 1)) variant = 9;
         switch (variant) {
             case 2: return launch_dma<256, 128, 4, 2>(g, stream);
             case 3: return launch_dma<256, 256, 2, 4>(g, stream);
             case 4: return launch_dma<128, 256, 2, 4>(g, stream);
             case 9: return launch_p8(g, stream);
+            case 11: return launch_p9(g, stream);
             case 201: return launch_dma<256, 256, 2, 4, 1>(g, stream);
             case 202: return launch_dma<256, 256, 2, 4, 2>(g, stream);
             case 203: return launch_dma<256, 256, 2, 4, 3>(g, stream);
