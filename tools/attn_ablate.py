@@ -3,12 +3,13 @@ sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"),
 import torch, ctypes
 import yvhip
 dev = "cuda:0"
-R, N, H = 128, 197, 12
+R, N, H = int(os.environ.get("ATTN_R", 128)), 197, 12
 g = torch.Generator().manual_seed(0)
 qkv = torch.randn(R * N, 3 * H * 64, generator=g).to(torch.bfloat16).to(dev)
 out = torch.zeros(R * N, H * 64, dtype=torch.bfloat16, device=dev)
 big = torch.zeros(64 * 1024 * 1024, device=dev)
-for abl in (0, 4, 1, 2, 3, 0, 4):   # 0 = shipped (online softmax per 32-key group), 4 = round-1 form, 1-3 = ablations of the round-1 form
+ref = None
+for abl in (0, 5, 11, 12, 13, 0, 5):   # 11 / 12 / 13: the pipelined kernel without fetches / compute / output stores (timing only)   # 0 = shipped (round 3: pipelined items, LDS-DMA staging, transposing V reads), 5 = round-2 one-item kernel, 4 = round-1 form
     yvhip.lib.yv_attention_debug(abl)
     ts = []
     for rd in range(5):
@@ -20,5 +21,7 @@ for abl in (0, 4, 1, 2, 3, 0, 4):   # 0 = shipped (online softmax per 32-key gro
             yvhip.attention(qkv, R, N, H, out)
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 10 * 1e3)
-    print(f"ablate={abl}: {sorted(ts)[2]:.1f} us")
+    o = out.float().clone()
+    if ref is None: ref = o
+    print(f"ablate={abl}: {sorted(ts)[2]:.1f} us  (R = {R}; max |diff| to the first variant {float((o - ref).abs().max()):.3g})")
 yvhip.lib.yv_attention_debug(0)

@@ -19,6 +19,7 @@
 //   (conflict-free ds_read_b128 for the 32-row A fragment); V^T rows are padded to
 //   2*NP+8 bytes (odd multiple of 8 B: conflict-free ds_read_b64 over 32 rows).
 #include "yv_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -292,6 +293,293 @@ __global__ __launch_bounds__(NT * 64, SINGLE ? 4 : 1) void attention_kernel(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-tile case, round 3 (N <= 32 NT <= 224: every ViT-x/16): a workgroup walks `per` consecutive (crop, head) items with K and V
+// DOUBLE-BUFFERED in LDS, so that item i+1's 2 x NP x 128 bytes are in flight while item i is computed (the one-item kernel was a
+// staging phase and a compute phase back to back, overlapped only by chance between the two workgroups of a CU):
+//   * K and V rows (128-byte strips of the 3 D-wide token rows = one cache line each) go global -> LDS by LDS-DMA, 8 pieces of
+//     8 rows per wave and tensor pair; no staging registers, no LDS stores, V is NOT transposed: the PV product's A operand
+//     (V^T: 32 d x 16 keys) is read from the row-major image with the transposing LDS read ds_read_b64_tr_b16 (two per fragment:
+//     keys kb + 4h + 0..3 and kb + 8 + 4h + 0..3 - the k order the exponentiated accumulator registers have);
+//   * images: K chunk ^ ((row >> 1) & 7) (conflict-free ds_read_b128 of the 32-row A fragment, as before); V chunk ^ 4 ((row >> 1) & 1):
+//     a 32-lane half of the transposing read takes rows q = 0..3 of a 4-key block, 64 bytes each; rows 0 / 2 (and 1 / 3) start
+//     on the same bank and the swizzle sends them to opposite halves of the 128-byte row.  Swizzles act on the DMA's SOURCE chunk;
+//   * one workgroup per CU (140 KB of LDS at NT = 7), so a wave may hold all NT score groups (16 NT registers): one softmax pass,
+//     no running maximum, no rescale;
+//   * one barrier per item: behind it item i has landed for every wave AND every wave is done with item i-1, whose buffer the
+//     DMA of item i+1 then refills; the output stores of item i-1 stay in flight across it (counted vmcnt);
+//   * output rows leave as 16-byte stores (v_permlane32_swap pairs the two half-waves' 8-byte pieces of a query row).
+// Rows past N are fetched from row N-1 (finite; their scores are masked to -inf, their probabilities are exactly 0).
+// ---------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* at_gptr_t;
+typedef __attribute__((address_space(3))) void* at_lptr_t;
+typedef __attribute__((ext_vector_type(4))) short at_s16x4;
+typedef __attribute__((address_space(3))) at_s16x4* at_lds_s16x4_t;
+
+// transposing reads of PV step n (inline asm: see the kernel) and the counted wait for them
+template <int N_>
+__device__ __forceinline__ void at_vread(u32x2 (&vr)[2][4], uint32_t va0, uint32_t va1) {
+    constexpr int off = (N_ >> 1) * 32 * 128 + (N_ & 1) * 16 * 128;
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"
+                 "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
+                 : "=&v"(vr[N_ & 1][0]), "=&v"(vr[N_ & 1][1]), "=&v"(vr[N_ & 1][2]), "=&v"(vr[N_ & 1][3])
+                 : "v"(va0), "v"(va1), "i"(off), "i"(off + 8 * 128) : "memory");
+}
+template <int N_, bool LAST>
+__device__ __forceinline__ void at_vwait(u32x2 (&vr)[2][4]) {
+    if constexpr (LAST) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[N_ & 1][0]), "+v"(vr[N_ & 1][1]), "+v"(vr[N_ & 1][2]), "+v"(vr[N_ & 1][3]) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vr[N_ & 1][0]), "+v"(vr[N_ & 1][1]), "+v"(vr[N_ & 1][2]), "+v"(vr[N_ & 1][3]) :: "memory");
+}
+
+template <int NT, int ABL = 0 /* timing only: 1 no K / V / Q fetch, 2 no compute, 3 no output stores */>
+__global__ __launch_bounds__(NT * 64) void attention_pipe_kernel(const uint16_t* __restrict__ qkv, int N, int H, int R, int per,
+                                                                  float scale_log2e, uint16_t* __restrict__ out,
+                                                                  const int32_t* __restrict__ r_dev, float* __restrict__ lse, AttnMx mx) {
+    constexpr int NP = NT * 32, TILE = NP * 128, BUF = 2 * TILE;
+    constexpr int PIECES = 2 * NT * 4;                          // 8-row pieces of K and V together; PIECES / NT = 8 per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Re = r_dev ? (r_dev[0] < R ? r_dev[0] : R) : R;
+    const int n_items = Re * H;
+    const int it0 = blockIdx.x * per;
+    const int it1 = it0 + per < n_items ? it0 + per : n_items;
+    if (it0 >= it1) return;
+    const int D = H * HD, ld = 3 * D;
+    const int rl = lane & 31, hh = lane >> 5;
+
+    // DMA source: lane (row = lane >> 3 of the piece, LDS chunk = lane & 7) fetches the chunk its LDS position holds.  Buffer form
+    // (32-bit offsets; the host checks the tensor is below 2 GB): behind the global_load_lds form hipcc waited vmcnt(0) in front of
+    // the first transposing LDS read of every item (it takes the DMA for a possible writer of the bytes read)
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, 0x7fffffff, 0x00020000);
+    auto issue = [&](int item, int buf) __attribute__((always_inline)) {
+        const int r = item / H, hd = item - r * H;
+        const uint32_t base = (uint32_t)(((size_t)r * N * ld + hd * HD) * 2);      // wave-uniform: the instruction's scalar offset
+        unsigned char* B = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pid = wave * 8 + j;                       // wave-uniform
+            const int tensor = pid >= NT * 4 ? 1 : 0;
+            const int prow = (pid - tensor * NT * 4) * 8;
+            const int row = prow + (lane >> 3), c = lane & 7;
+            const int key = row < N ? row : N - 1;
+            const int cs = tensor ? (c ^ (((row >> 1) & 1) << 2)) : (c ^ ((row >> 1) & 7));
+            const uint32_t voff = (uint32_t)((key * ld + (tensor + 1) * D + cs * 8) * 2);
+            if (ABL != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (at_lptr_t)(B + tensor * TILE + prow * 128), 16, (int)voff, (int)base, 0, 0);
+        }
+    };
+    // Query rows: by LDS-DMA as well, into ONE buffer: a wave reads only its own 32 rows, so it refills them (item i+1) right after
+    // its own S MFMAs of item i, no barrier involved.  (Ordinary loads to registers made hipcc wait vmcnt(0) - drain the DMA of item
+    // i+1 - before their first use: staging and compute ran back to back, 13 + 30 us; hidden in inline asm, the loop-carried
+    // registers were copied by compiler-placed moves before the data had landed.)
+    auto issue_q = [&](int item) __attribute__((always_inline)) {
+        const int r = item / H, hd = item - r * H;
+        const uint32_t base = (uint32_t)(((size_t)r * N * ld + hd * HD) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int prow = wave * 32 + j * 8;
+            const int row = prow + (lane >> 3), c = lane & 7;
+            const int qr = row < N ? row : N - 1;
+            const uint32_t voff = (uint32_t)((qr * ld + ((c ^ ((row >> 1) & 7)) << 3)) * 2);
+            if (ABL != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (at_lptr_t)(smem + 2 * BUF + prow * 128), 16, (int)voff, (int)base, 0, 0);
+        }
+    };
+    // V^T fragment addressing of the transposing read (see above): 16-lane group G = lane >> 4 takes d columns (G & 1) * 16 .. + 15
+    // of the key rows kb + 4 (G >> 1) + q; lane 4 q + p of the group addresses row q, columns 4 p .. 4 p + 3
+    const int tG = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int tkq = 4 * (tG >> 1) + tq;
+    const int tsw = ((tkq >> 1) & 1) << 2;
+    const int tc = (tG & 1) * 2 + (tp >> 1);
+    const int voff0 = tkq * 128 + (((0 ^ tsw) + tc) << 4) + (tp & 1) * 8;      // mt = 0: chunks 0..3
+    const int voff1 = tkq * 128 + (((4 ^ tsw) + tc) << 4) + (tp & 1) * 8;      // mt = 1: chunks 4..7
+
+    const bool plain = !lse && !mx.q && ABL == 0;                          // exactly 4 output stores per wave and item (the counted wait below)
+    issue(it0, 0);
+    issue_q(it0);
+    for (int item = it0; item < it1; ++item) {
+        const int buf = (item - it0) & 1;
+        const bool more = item + 1 < it1;
+        // item's K / V have landed (this wave's pieces; the barrier covers the others'); the previous item's output stores - the
+        // youngest memory operations - stay in flight
+        if (item > it0 && plain) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(item + 1, buf ^ 1);
+        const unsigned char* Ks = smem + buf * BUF;
+        const unsigned char* Vs = Ks + TILE;
+        if (ABL == 2) { if (more) issue_q(item + 1); continue; }
+        bf16x8 fq[4];
+        {
+            const int row = wave * 32 + rl;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fq[ks] = *(const bf16x8*)(smem + 2 * BUF + row * 128 + (((2 * ks + hh) ^ ((row >> 1) & 7)) << 4));
+        }
+
+        // ---- S^T = K . Q^T: all NT groups ----------------------------------------------------
+        // (the four K fragments of group kt+1 are read before group kt's MFMAs: left to itself hipcc reads every fragment into the same
+        // four registers right before its MFMA and waits lgkmcnt(0) for it - 28 exposed LDS round trips per item)
+        f32x16 s[NT];
+        bf16x8 kf[2][4];
+        auto read_k = [&](int kt, bf16x8 (&f)[4]) __attribute__((always_inline)) {
+            const int row = kt * 32 + rl;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) f[ks] = *(const bf16x8*)(Ks + row * 128 + (((2 * ks + hh) ^ ((row >> 1) & 7)) << 4));
+        };
+        read_k(0, kf[0]);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt + 1 < NT) read_k(kt + 1, kf[(kt + 1) & 1]);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt & 1][ks], fq[ks], s[kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) issue_q(item + 1);                          // this wave's query rows had their last use (the fragments are in registers)
+        // ---- softmax over the register axis + lane ^ 32, in two passes: the maximum first (it follows the S MFMAs group by group),
+        // then exp / sum / pack of group kt+1 INTERLEAVED with the four PV MFMAs of group kt: left alone hipcc emits 28 S MFMAs, one
+        // block of ~450 vector instructions, 28 PV MFMAs - neither pipe ever works beside the other (measured: 32 us of compute per
+        // 128 crops for 7 us of MFMA time) ---------------------------------------------------------
+        float mxv = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt == NT - 1) {                                   // only the last group can straddle N (N > 32 (NT - 1)); branch-free
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    s[kt][e] = key < N ? s[kt][e] : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mxv = fmaxf(mxv, s[kt][e]);
+        }
+        mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
+        const float mb = mxv * scale_log2e;
+        float l0 = 0.f, l1 = 0.f;
+        bf16x8 fp[NT][2];
+        auto expg = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kt][e], scale_log2e, -mb));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kt][e + 1], scale_log2e, -mb));
+                l0 += p0; l1 += p1;
+                fp[kt][e >> 3][e & 7] = (__bf16)p0; fp[kt][e >> 3][(e & 7) + 1] = (__bf16)p1;
+            }
+        };
+        f32x16 o[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[mt][e] = 0.f;
+        // The transposing reads are inline asm (their builtin makes hipcc wait vmcnt(0) - drain item i+1's DMA - before the first
+        // one: it cannot see that they read the OTHER buffer), so their completion is counted by hand: the four reads of step n+1
+        // are issued before the wait for step n's (lgkmcnt(4): LDS results return in order; LDS operations hipcc issues in between
+        // only make the wait stricter).  Step n = (key group kt, 16-key half st); a step's reads: (mt 0, mt 1) x (keys +0..3, +8..11).
+        u32x2 vr[2][4];
+        const uint32_t vbase = (uint32_t)(uintptr_t)(at_lptr_t)(const_cast<unsigned char*>(Vs));
+        const uint32_t va0 = vbase + voff0, va1 = vbase + voff1;
+        auto pv_step = [&](auto n_c) __attribute__((always_inline)) {
+            constexpr int n = decltype(n_c)::value, kt = n >> 1, st = n & 1;
+            if constexpr (n + 1 < 2 * NT) at_vread<n + 1>(vr, va0, va1);
+            at_vwait<n, !(n + 1 < 2 * NT)>(vr);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const u32x4 pkv = {vr[n & 1][2 * mt][0], vr[n & 1][2 * mt][1], vr[n & 1][2 * mt + 1][0], vr[n & 1][2 * mt + 1][1]};
+                o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pkv), fp[kt][st], o[mt], 0, 0, 0);
+            }
+        };
+        expg(0);
+        at_vread<0>(vr, va0, va1);
+        auto pv_group = [&](auto kt_c) __attribute__((always_inline)) {
+            constexpr int kt = decltype(kt_c)::value;
+            if constexpr (kt < NT) {
+                pv_step(std::integral_constant<int, 2 * kt>{});
+                pv_step(std::integral_constant<int, 2 * kt + 1>{});
+                if constexpr (kt + 1 < NT) expg(kt + 1);
+            }
+        };
+        pv_group(std::integral_constant<int, 0>{}); pv_group(std::integral_constant<int, 1>{}); pv_group(std::integral_constant<int, 2>{});
+        pv_group(std::integral_constant<int, 3>{}); pv_group(std::integral_constant<int, 4>{}); pv_group(std::integral_constant<int, 5>{});
+        pv_group(std::integral_constant<int, 6>{});
+        const float l = (l0 + l1) + __shfl_xor(l0 + l1, 32, 64);
+        // ---- normalise and store -------------------------------------------------------------------
+        const int r = item / H, hd = item - r * H;
+        const int q = wave * 32 + rl;
+        const float inv = 1.0f / l;
+        if (lse && hh == 0 && q < N) lse[((size_t)r * H + hd) * N + q] = mb + log2f(l);              // log2 domain
+        if (mx.q) {
+            if (q < N) {
+                const long long row = (long long)r * N + q;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float f[16], amax = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { f[k] = bf16_to_f32(f32_to_bf16(o[mt][k] * inv)); amax = fmaxf(amax, fabsf(f[k])); }
+                    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                    int e = -127;
+                    if (amax > 0.f) {
+                        int ex;
+                        const float mant = frexpf(amax * (1.0f / 448.0f), &ex);
+                        e = mant == 0.5f ? ex - 1 : ex;
+                        e = e < -127 ? -127 : (e > 127 ? 127 : e);
+                    }
+                    const float is = ldexpf(1.0f, -e);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        int pq = 0;
+                        pq = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * g4] * is, f[4 * g4 + 1] * is, pq, false);
+                        pq = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * g4 + 2] * is, f[4 * g4 + 3] * is, pq, true);
+                        *(uint32_t*)(mx.q + row * mx.ldq + hd * HD + mt * 32 + 8 * g4 + 4 * hh) = (uint32_t)pq;
+                    }
+                    if (hh == 0) {
+                        const int bk = hd * 2 + mt;
+                        mx.s[((long long)(bk >> 2) * mx.rows + row) * 4 + (bk & 3)] = (uint8_t)(e + 127);
+                    }
+                }
+            }
+        } else {
+            // a lane holds d = 32 mt + 8 g + 4 hh .. + 3 of its query; pairs of groups (g, g + 1) are exchanged between the half-waves
+            // so that lane hh = 0 owns d = 8 g .. 8 g + 7 and lane hh = 1 owns d = 8 (g + 1) .. + 7: 8 stores of 16 bytes
+            const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7fffffff, 0x00020000);   // (offsets checked by the host: < 2 GB)
+            const uint32_t ob = q < N ? (uint32_t)((((size_t)r * N + q) * D + hd * HD) * 2) : 0x80000000u;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4 += 2) {
+                    uint32_t a0 = pack_bf16x2(o[mt][4 * g4] * inv, o[mt][4 * g4 + 1] * inv);
+                    uint32_t a1 = pack_bf16x2(o[mt][4 * g4 + 2] * inv, o[mt][4 * g4 + 3] * inv);
+                    uint32_t b0 = pack_bf16x2(o[mt][4 * g4 + 4] * inv, o[mt][4 * g4 + 5] * inv);
+                    uint32_t b1 = pack_bf16x2(o[mt][4 * g4 + 6] * inv, o[mt][4 * g4 + 7] * inv);
+                    const auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    const u32x4 pkv = {x0[0], x1[0], x0[1], x1[1]};
+                    if (ABL != 3) __builtin_amdgcn_raw_buffer_store_b128(pkv, rsO, ob + (uint32_t)((mt * 32 + 8 * (g4 + hh)) * 2), 0, 0);
+                    else asm volatile("" :: "v"(pkv));
+                }
+        }
+    }
+}
+
+template <int NT>
+int launch_attn_pipe(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t* out, const int32_t* r_dev, float* lse,
+                     hipStream_t st, AttnMx mx) {
+    constexpr int NP = NT * 32;
+    const size_t lds = (size_t)5 * NP * 128;                   // K, V double-buffered + this item's query rows
+    auto kern = g_attn_abl == 11 ? attention_pipe_kernel<NT, 1> : g_attn_abl == 12 ? attention_pipe_kernel<NT, 2> :
+                g_attn_abl == 13 ? attention_pipe_kernel<NT, 3> : attention_pipe_kernel<NT, 0>;
+    if (lds > 65536 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return YV_ERR_LAUNCH;
+    // items per workgroup: enough to amortise the pipeline fill, few enough that the grid still fills and balances the chip
+    const int items = R * H;
+    int per = items / 256;
+    per = per < 1 ? 1 : (per > 6 ? 6 : per);
+    const int grid = (items + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, st, qkv, N, H, R, per, scale * 1.4426950408889634f, out, r_dev, lse, mx);
+    return yv_launch_status();
+}
+
 template <int NT>
 int launch_attn(const uint16_t* qkv, int R, int N, int H, float scale, uint16_t* out, const int32_t* r_dev, float* lse,
                 hipStream_t st, AttnMx mx) {
@@ -320,6 +608,17 @@ static int attention_impl(const void* qkv, int R, int N, int H, float scale, voi
     uint16_t* o = (uint16_t*)out;
     hipStream_t st = (hipStream_t)stream;
     const int nt = N > 256 ? 8 : (N + 31) / 32;        // > 256 tokens: 256-row tiles, online softmax
+    if (nt <= 7 && (g_attn_abl == 0 || g_attn_abl > 10) && (long long)R * N * H * HD * 6 < 0x7fffffffLL) {      // single tile: the pipelined kernel
+        switch (nt) {
+            case 1: return launch_attn_pipe<1>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+            case 2: return launch_attn_pipe<2>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+            case 3: return launch_attn_pipe<3>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+            case 4: return launch_attn_pipe<4>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+            case 5: return launch_attn_pipe<5>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+            case 6: return launch_attn_pipe<6>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+            default: return launch_attn_pipe<7>(q, R, N, H, scale, o, r_dev, lse, st, mx);
+        }
+    }
     switch (nt) {
         case 1: return launch_attn<1>(q, R, N, H, scale, o, r_dev, lse, st, mx);
         case 2: return launch_attn<2>(q, R, N, H, scale, o, r_dev, lse, st, mx);
