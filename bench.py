@@ -25,8 +25,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0        # bf16 dense, MI355X_MICROARCH.md chip table
-DOMINANT_KERNEL = "gemm_p8_kernel"       # what profiles/pmc_traffic.json must have been collected for
-ROUND_TAG = "r02"
+DOMINANT_KERNEL = "gemm_p9_kernel"       # what profiles/pmc_traffic.json must have been collected for
+ROUND_TAG = "r03"
 
 
 def _cpu_loop(imgs, yolo_sd, vit_sd, vit_name, crops, budget_s, max_images):
@@ -260,28 +260,51 @@ def live_traffic(argv_tail):
     import shutil
     import subprocess
     import tempfile
+    import signal
     prof = shutil.which("rocprofv3")
-    if prof is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
-        return None
+    if prof is None:
+        return {"failed": "rocprofv3 not found"}
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return {"failed": "already running under a profiler"}
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="yv_pmc_", dir="/tmp")
+        proc = None
         try:
             cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__)] + argv_tail + ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-traffic"]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
-            if r.returncode != 0:
-                return None
+            # own session: on a timeout the WHOLE group (profiler + the profiled bench it started) is killed and reaped before the
+            # timed run begins - a surviving child would share the GPU with it
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                print(f"[bench] live traffic pass {counter}: timed out, process group killed", file=sys.stderr)
+                return {"failed": f"{counter} pass timed out"}
+            if rc != 0:
+                print(f"[bench] live traffic pass {counter}: rocprofv3 exit code {rc}", file=sys.stderr)
+                return {"failed": f"{counter} pass: rocprofv3 exit code {rc}"}
             rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 rows += [float(x["Counter_Value"]) for x in csv.DictReader(open(f))
                          if DOMINANT_KERNEL in x["Kernel_Name"] and x["Counter_Name"] == counter]
             if not rows:
-                return None
+                print(f"[bench] live traffic pass {counter}: no {DOMINANT_KERNEL} dispatches in the counter file", file=sys.stderr)
+                return {"failed": f"{counter} pass: no {DOMINANT_KERNEL} dispatches recorded"}
             vals[counter] = (sum(rows) / len(rows), len(rows))
-        except Exception:
-            return None
+        except Exception as e:                                    # noqa: BLE001 - any failure here only costs the live number
+            if proc is not None and proc.poll() is None:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+            print(f"[bench] live traffic pass {counter}: {type(e).__name__}: {e}", file=sys.stderr)
+            return {"failed": f"{counter} pass: {type(e).__name__}"}
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return {"bytes_per_launch": (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0,
@@ -420,7 +443,8 @@ def main():
         # (tools/profile_summary.py -> profiles/pmc_traffic.json).  The file names the kernel and the round it was collected
         # for; anything else (other kernel, older round) is reported as null instead of a stale number.
         traffic, traffic_source = None, None
-        if live is not None:
+        live_failed = live.get("failed") if live is not None else None
+        if live is not None and live_failed is None:
             traffic = live["bytes_per_launch"]
             traffic_source = (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command before the timed run, "
                               f"{live['launches'][0]} / {live['launches'][1]} dispatches; 2 x FETCH + WRITE")
@@ -430,7 +454,8 @@ def main():
                 tj = json.load(open(pmc))
                 if tj.get("kernel") == DOMINANT_KERNEL and tj.get("round") == ROUND_TAG:
                     traffic = tj.get("bytes_per_launch")
-                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 passes of this round over this command)"
+                    traffic_source = ("fallback: profiles/pmc_traffic.json (rocprofv3 passes of this round over this command)" +
+                                      (f"; live passes failed: {live_failed}" if live_failed else "; live passes not requested"))
             except Exception:
                 traffic = None
         line = {
@@ -450,12 +475,12 @@ def main():
                                    ("HIP streams: detector of batch i+1 (high priority) overlaps classifier of batch i" +
                                     ("" if args.no_split else "; classifier runs as two concurrent half-batches")),
                        "weights": "random-init, seed 42",
-                       "gemm": "persistent 8-phase kernel, tile height per launch" +
+                       "gemm": "persistent free-running kernel (gemm_p9), tile height per launch" +
                                ("" if runner is None else ", 208 of 256 CUs (the rest stay free for the concurrent streams)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS * (2.0 if args.dtype == "mxfp8" else 1.0),
                          "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_TFLOPS * (2.0 if args.dtype == "mxfp8" else 1.0)),
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": ("gemm_p8_kernel (qkv / proj / fc1 / fc2) + gemm_dma_kernel<128,128> (patch-embed, head)" if args.dtype == "bf16" else
+                         "kernel": ("gemm_p9_kernel (qkv / proj / fc1 / fc2) + gemm_dma_kernel<128,128> (patch-embed, head)" if args.dtype == "bf16" else
                                     "gemm_mx_kernel<128,128> (block linears, block-scaled MFMA peak) + gemm_dma_kernel (patch-embed, head)"),
                          "launches": n_launch,
                          "avg_launch_us": ms * 1e3 / max(n_launch, 1), "kernel_busy_ms_per_step": busy / max(len(sampled), 1), "instrumented_steps": len(sampled),

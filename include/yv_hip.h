@@ -41,6 +41,10 @@ int yv_device_is_gfx950(void);
 /* Tuning knobs (process-wide, not part of the reference surface): "linear_variant" (0 register-staged
  * 128x128, 1 LDS-DMA 128x128, 2 256x128, 3 256x256, 4 128x256), "linear_group_m" (M tiles per L2 group). */
 int yv_set_option(const char* key, int value);
+/* Current value of a knob.  "linear_p8_cus" (workgroups of the persistent classifier GEMMs; 0 = every CU) is PER THREAD: it
+ * applies to the launches the calling thread makes (a pipelined runner lowers it around its own classifier submissions so that
+ * kernels of its other streams find free CUs, and restores it; other threads and later callers are not affected). */
+int yv_get_option(const char* key, int* value);
 
 /* MXFP8 linears (BASELINE.json configs[4], FP8 classifier GEMMs; OCP e4m3 bytes + one E8M0 scale per 32 consecutive K
  * elements of a row, consumed by the block-scaled gfx950 MFMA).
@@ -138,6 +142,12 @@ int yv_postprocess_dets(const int32_t* num_dets, const float* bboxes, const floa
  * Order: image ascending, then detection (score) order.  Rows >= total are zeroed. */
 int yv_compact_crops(const int32_t* det_count, const int32_t* crop_rect, const int32_t* crop_ok, int B, int slots,
                      int cap, int32_t* crop_list, int32_t* crop_total, void* stream);
+/* The same, for a classifier that runs the crop list as `parts` (<= 64) equal slices of ceil(cap / parts) entries on concurrent
+ * streams (reference site: the per-image loop of YOLOTensorRT inferdet.main, YOLOTensorRT_yolodet_py_解读.md:57-116 - batch
+ * assembly has no reference counterpart): crop_total (1 + parts) i32 = {total, crops in slice 0, crops in slice 1, ...}, so
+ * that no host-side or torch arithmetic on the device-resident count is needed between detect and classify. */
+int yv_compact_crops_split(const int32_t* det_count, const int32_t* crop_rect, const int32_t* crop_ok, int B, int slots,
+                           int cap, int parts, int32_t* crop_list, int32_t* crop_total, void* stream);
 
 /* crop + A.Resize(224,224,INTER_NEAREST) + A.Normalize(.5,.5) + HWC->CHW
  * (utils/trainClass.py:92,218-221,265-266; app.py:39-42).

@@ -23,7 +23,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 for rd in range(5):
     for c in cus:
-        yvhip.set_option("linear_p8_cus", c)
+        runner.gemm_cus = c
         runner.submit(images); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):

@@ -15,7 +15,7 @@ pipe = DetectClassifyPipeline(engines.YoloEngine(engines.init_yolo_state("n", 5,
                               max_crops_per_image=4)
 g = torch.Generator().manual_seed(1234)
 images = torch.randint(0, 256, (32, 640, 640, 3), generator=g, dtype=torch.uint8).to(dev)
-runner = PipelinedRunner(pipe, split_classifier=True)      # sets linear_p8_cus = 208
+runner = PipelinedRunner(pipe, split_classifier=True)      # gemm_cus = 208 around its classifier submissions
 det = pipe.detect_stage(images)
 torch.cuda.synchronize()
 print("crops:", int(det["crop_total"]))
@@ -23,7 +23,7 @@ subs = [torch.cuda.Stream(), torch.cuda.Stream()]
 
 def full(cus):
     def run():
-        yvhip.set_option("linear_p8_cus", cus)
+        runner.gemm_cus = cus
         runner.submit(images)
     return run
 

@@ -1432,7 +1432,7 @@ int launch_p8_inst(GemmArgs& g, hipStream_t st, int n_cu) {
 }
 
 int g_opt_p8_sched = 1;            // tile schedule of the persistent kernel (GemmArgs::sched): "linear_p8_sched"
-int g_opt_p8_cus = 0;              // persistent grid size; 0 = every CU ("linear_p8_cus": leave CUs to concurrent streams)
+thread_local int g_opt_p8_cus = 0; // persistent grid size OF LAUNCHES MADE BY THIS THREAD; 0 = every CU ("linear_p8_cus": leave CUs to concurrent streams)
 int g_opt_p8_rows = 0;             // 0 = pick the tile height per launch; 128 / 160 / 192 / 224 / 256 force it ("linear_p8_rows")
 
 int launch_p8(GemmArgs& g, hipStream_t st) {
@@ -2175,6 +2175,21 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!strcmp(key, "linear_p8_sched")) { g_opt_p8_sched = value; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_splitk")) { g_opt_linear_splitk = value; return YV_OK; }
+    return YV_ERR_ARG;
+}
+
+extern "C" int yv_get_option(const char* key, int* value) {
+    if (!key || !value) return YV_ERR_ARG;
+    if (!strcmp(key, "linear_variant")) { *value = g_opt_variant; return YV_OK; }
+    if (!strcmp(key, "wgrad_split_cap")) { *value = g_opt_wgrad_cap; return YV_OK; }
+    if (!strcmp(key, "linear_group_m")) { *value = g_opt_group_m; return YV_OK; }
+    if (!strcmp(key, "staged_epilogue")) { *value = g_opt_staged; return YV_OK; }
+    if (!strcmp(key, "linear_p8")) { *value = g_opt_p8; return YV_OK; }
+    if (!strcmp(key, "linear_p8_rows")) { *value = g_opt_p8_rows; return YV_OK; }
+    if (!strcmp(key, "linear_p8_cus")) { *value = g_opt_p8_cus; return YV_OK; }
+    if (!strcmp(key, "linear_p8_sched")) { *value = g_opt_p8_sched; return YV_OK; }
+    if (!strcmp(key, "conv_splitk")) { *value = g_opt_splitk; return YV_OK; }
+    if (!strcmp(key, "linear_splitk")) { *value = g_opt_linear_splitk; return YV_OK; }
     return YV_ERR_ARG;
 }
 

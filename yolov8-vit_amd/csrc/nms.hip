@@ -13,6 +13,7 @@
 // intrinsics: no FMA contraction, IEEE divide) in torchvision's operation
 // order, which is what makes the keep list bit-exact against the reference.
 #include "yv_common.h"
+#include <atomic>
 
 namespace {
 
@@ -1267,7 +1268,7 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
 }
 
 __global__ void compact_crops_kernel(const int32_t* __restrict__ det_count, const int32_t* __restrict__ crop_rect,
-                                     const int32_t* __restrict__ crop_ok, int B, int slots, int cap,
+                                     const int32_t* __restrict__ crop_ok, int B, int slots, int cap, int parts,
                                      int32_t* __restrict__ crop_list, int32_t* __restrict__ crop_total) {
     // single workgroup: images are few (<= a few thousand); order = image, then detection rank
     __shared__ int32_t base_sh;
@@ -1306,6 +1307,13 @@ __global__ void compact_crops_kernel(const int32_t* __restrict__ det_count, cons
         o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0;
     }
     if (tid == 0) crop_total[0] = total;
+    // counts of `parts` equal slices of the list (ceil(cap / parts) entries each; the classifier runs the slices on concurrent streams)
+    if (tid < parts) {
+        const int base = (cap + parts - 1) / parts, lo = tid * base;
+        const int n = cap - lo < base ? (cap - lo > 0 ? cap - lo : 0) : base;
+        const int c = total - lo;
+        crop_total[1 + tid] = c < 0 ? 0 : (c > n ? n : c);
+    }
 }
 
 }  // namespace
@@ -1417,16 +1425,20 @@ extern "C" int yv_efficient_nms_ws(const float* boxes, const float* scores, int 
     auto lds_of = [&](int cap, int nw) { return (size_t)cap * (8 + 16) + (size_t)max_out * 16 + 128 * 8 + (size_t)nw * 8 + 16; };
     const size_t head_dyn = (size_t)max_out * (16 + 8 + 2) + 16;
     const size_t lds1 = lds_of(EN_MAXK, 16) > head_dyn ? lds_of(EN_MAXK, 16) : head_dyn, lds0 = lds_of(1024, 4);
-    static size_t attr_front = 0, attr_classes = 0;             // dynamic-LDS limits already granted (they only ever grow)
-    if (lds1 > attr_front) {
+    // dynamic-LDS limits already granted, PER DEVICE (the attribute belongs to the device's copy of the kernel; they only ever grow;
+    // atomics: request threads of different streams may race here - the worst case is a repeated, idempotent grant)
+    static std::atomic<size_t> attr_front[64], attr_classes[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return YV_ERR_LAUNCH;
+    if (lds1 > attr_front[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)en2_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess)
             return YV_ERR_LAUNCH;
-        attr_front = lds1;
+        attr_front[dev].store(lds1, std::memory_order_release);
     }
-    if (lds0 > 32768 && lds0 > attr_classes) {
+    if (lds0 > 32768 && lds0 > attr_classes[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)en2_classes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0) != hipSuccess)
             return YV_ERR_LAUNCH;
-        attr_classes = lds0;
+        attr_classes[dev].store(lds0, std::memory_order_release);
     }
     hipLaunchKernelGGL(en2_front_kernel, dim3(B), dim3(EN_THREADS), lds1, st, boxes, scores, A, nc, score_threshold, iou_threshold,
                        max_out, pre_topk, w, num_dets, out_boxes, out_scores, out_labels);
@@ -1467,7 +1479,16 @@ extern "C" int yv_compact_crops(const int32_t* det_count, const int32_t* crop_re
     if (B < 0 || slots <= 0 || cap < 0 || !det_count || !crop_rect || !crop_ok || !crop_list || !crop_total)
         return YV_ERR_ARG;
     hipLaunchKernelGGL(compact_crops_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, det_count, crop_rect,
-                       crop_ok, B, slots, cap, crop_list, crop_total);
+                       crop_ok, B, slots, cap, 0, crop_list, crop_total);
+    return yv_launch_status();
+}
+
+extern "C" int yv_compact_crops_split(const int32_t* det_count, const int32_t* crop_rect, const int32_t* crop_ok, int B,
+                                      int slots, int cap, int parts, int32_t* crop_list, int32_t* crop_total, void* stream) {
+    if (B < 0 || slots <= 0 || cap < 0 || parts < 0 || parts > 64 || !det_count || !crop_rect || !crop_ok || !crop_list || !crop_total)
+        return YV_ERR_ARG;
+    hipLaunchKernelGGL(compact_crops_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, det_count, crop_rect,
+                       crop_ok, B, slots, cap, parts, crop_list, crop_total);
     return yv_launch_status();
 }
 

@@ -151,8 +151,16 @@ __global__ __launch_bounds__(256) void wrapper_head_kernel(const float* __restri
     __shared__ float h[WH_HID];
     __shared__ float lg[WH_MAX_NC];
     const int r = blockIdx.x;
-    if (r_dev && r >= r_dev[0]) return;
     const int tid = threadIdx.x;
+    if (r_dev && r >= r_dev[0]) {
+        // rows past the device-side crop count: logits 0, label -1 (written by the first ensemble member, so that the caller
+        // need not zero / fill its output tensors with two more launches per batch)
+        if (!accumulate) {
+            if (tid < nc) logits[(size_t)r * nc + tid] = 0.f;
+            if (tid == 0) labels[r] = -1;
+        }
+        return;
+    }
     for (int i = tid; i < WH_FEAT; i += 256) f[i] = fmaxf(feats[(size_t)r * ldf + i], 0.f);     // ReLU
     __syncthreads();
     {

@@ -52,6 +52,7 @@ _SIGS = {
     "yv_error_string": (C.c_char_p, [_i]),
     "yv_device_is_gfx950": (_i, []),
     "yv_set_option": (_i, [C.c_char_p, _i]),
+    "yv_get_option": (_i, [C.c_char_p, _vp]),
     "yv_set_workspace": (_i, [_vp, _vp, _sz]),
     "yv_set_launch_timing": (_i, [_vp, _vp]),
     "yv_linear_mxfp8_q": (_i, [_vp, C.c_longlong, _vp, C.c_longlong, _vp, _vp, C.c_longlong, _vp, _i, _i, _i, _i, _vp, _i, _vp,
@@ -70,6 +71,7 @@ _SIGS = {
     "yv_postprocess_dets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _i, _i,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yv_compact_crops": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "yv_compact_crops_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "yv_crop_resize_norm": (_i, [_vp, _i, _i, _i, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "yv_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "yv_augment_patchify": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -149,6 +151,12 @@ _bind()
 
 def set_option(key: str, value: int):
     check(lib.yv_set_option(key.encode(), int(value)), "yv_set_option")
+
+
+def get_option(key: str) -> int:
+    v = C.c_int(0)
+    check(lib.yv_get_option(key.encode(), C.byref(v)), "yv_get_option")
+    return int(v.value)
 
 
 def check(code: int, what: str = ""):
@@ -277,14 +285,20 @@ def postprocess_dets(num_dets, bboxes, scores, labels, ratio, dwdh, img_wh, conf
     return out
 
 
-def compact_crops(det_count, crop_rect, crop_ok, cap: int):
+def compact_crops(det_count, crop_rect, crop_ok, cap: int, parts: int = 0):
+    """-> crop_list (cap, 6) i32, total (1,) i32.  parts > 0: total is (1 + parts,) = {total, crops in each of `parts` equal
+    slices of ceil(cap / parts) entries} (device-side: the classifier's concurrent half-batches read their counts from it)."""
     _chk_dev(det_count, crop_rect, crop_ok)
     B, slots = crop_ok.shape
     dev = crop_ok.device
     crop_list = torch.empty((max(cap, 1), 6), dtype=torch.int32, device=dev)
-    total = torch.empty((1,), dtype=torch.int32, device=dev)
-    check(lib.yv_compact_crops(_p(det_count), _p(crop_rect), _p(crop_ok), B, slots, cap, _p(crop_list), _p(total),
-                               _st()), "yv_compact_crops")
+    total = torch.empty((1 + max(parts, 0),), dtype=torch.int32, device=dev)
+    if parts > 0:
+        check(lib.yv_compact_crops_split(_p(det_count), _p(crop_rect), _p(crop_ok), B, slots, cap, parts, _p(crop_list),
+                                         _p(total), _st()), "yv_compact_crops_split")
+    else:
+        check(lib.yv_compact_crops(_p(det_count), _p(crop_rect), _p(crop_ok), B, slots, cap, _p(crop_list), _p(total),
+                                   _st()), "yv_compact_crops")
     return crop_list, total
 
 

@@ -205,10 +205,16 @@ class YoloEngine:
                out, 0, EPI_SILU)
 
     def forward_raw(self, images: torch.Tensor):
-        """Runs backbone+neck+head; returns per-scale (box logits f32, class logits f32) NHWC buffers (engine-owned:
-        hold `self.guard` across the call and the consumption of the result when other threads may use the engine)."""
+        """Runs backbone+neck+head; returns per-scale (box logits f32, class logits f32) NHWC tensors.  Called with `self.guard`
+        held (as __call__ does) the engine-owned buffers themselves are returned - valid until the caller leaves the guard;
+        called bare, the result is CLONED under the guard, so that another thread's next replay cannot overwrite what this
+        caller is still reading."""
+        outer = self.guard.held
         with self.guard:
-            return self._forward_raw(images)
+            res = self._forward_raw(images)
+            if outer:
+                return res
+            return tuple([t.clone() for t in part] for part in res)
 
     def _forward_raw(self, images: torch.Tensor):
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3:
@@ -402,8 +408,10 @@ class VitEngine:
 
     def backbone(self, patches: torch.Tensor, cap: int, count: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
         """patches (cap*tok, 3*P*P) bf16 -> feats (cap,1024) f32 (columns >= 1000 are zero padding)."""
+        outer = self.guard(slot).held
         with self.guard(slot):
-            return self._backbone(patches, cap, count, slot)
+            feats = self._backbone(patches, cap, count, slot)
+            return feats if outer else feats.clone()         # bare call: a copy that the next replay cannot overwrite
 
     def _backbone(self, patches: torch.Tensor, cap: int, count: Optional[torch.Tensor], slot: int) -> torch.Tensor:
         b = self._buffers(cap, slot)

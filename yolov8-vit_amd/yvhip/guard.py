@@ -24,11 +24,18 @@ class StepGuard:
         self._depth = 0
         self._stream = None
         self._stream_fn = stream_fn
+        self._owner = None
         self.entries = 0
+
+    @property
+    def held(self) -> bool:
+        """True when the CALLING thread is inside the guard (its engine-owned results stay valid until it leaves)."""
+        return self._owner == threading.get_ident() and self._depth > 0
 
     def __enter__(self):
         self._lock.acquire()
         self._depth += 1
+        self._owner = threading.get_ident()
         if self._depth == 1:
             self.entries += 1
             cur = self._stream_fn()
@@ -39,6 +46,7 @@ class StepGuard:
     def __exit__(self, *exc):
         if self._depth == 1:
             self._stream = self._stream_fn()
+            self._owner = None
         self._depth -= 1
         self._lock.release()
         return False

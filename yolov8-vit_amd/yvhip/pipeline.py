@@ -32,6 +32,7 @@ class DetectClassifyPipeline:
         self.conf, self.dedupe_iou, self.coord_mode = conf, dedupe_iou, coord_mode
         self.max_crops = max_crops_per_image
         self.capacity = crops_capacity
+        self.parts = 2                                    # slices whose counts detect_stage publishes (PipelinedRunner: one per stream)
         self._const: Dict[int, dict] = {}
 
     def _identity_geometry(self, B: int, S: int, dev):
@@ -58,9 +59,12 @@ class DetectClassifyPipeline:
                                 self.max_crops)
         per_img = self.max_crops if self.max_crops > 0 else self.topk
         cap = self.capacity if self.capacity else B * per_img
-        crop_list, total = compact_crops(post["det_count"], post["crop_rect"], post["crop_ok"], cap)
+        # (the counts of the classifier's concurrent slices come out of the same kernel: torch arithmetic on the device-side count
+        # was four small dependent launches at the head of every classifier pass)
+        crop_list, totals = compact_crops(post["det_count"], post["crop_rect"], post["crop_ok"], cap, parts=self.parts)
         out = dict(post)
-        out.update(num_dets=num, bboxes=bb, scores=sc, labels=lb, crop_list=crop_list, crop_total=total, capacity=cap)
+        out.update(num_dets=num, bboxes=bb, scores=sc, labels=lb, crop_list=crop_list, crop_total=totals[:1], capacity=cap,
+                   crop_part_counts=totals[1:])
         return out
 
     def classify_stage(self, src: torch.Tensor, det: dict, streams: Optional[Sequence[torch.cuda.Stream]] = None) -> dict:
@@ -71,8 +75,8 @@ class DetectClassifyPipeline:
         cap, crop_list, total = det["capacity"], det["crop_list"], det["crop_total"]
         dev = src.device
         v0 = self.vits[0]
-        logits = torch.zeros((cap, v0.nc), dtype=torch.float32, device=dev)
-        labels = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+        logits = torch.empty((cap, v0.nc), dtype=torch.float32, device=dev)     # rows past the crop count: 0 / -1, written by the
+        labels = torch.empty((cap,), dtype=torch.int32, device=dev)             # head kernel of the first ensemble member
         w = 1.0 / len(self.vits)                      # ensemble = mean of logits (defined by this build)
         parts = [(0, cap, total, 0, None)]
         if streams is not None and len(streams) >= 2 and cap >= len(streams):
@@ -82,7 +86,11 @@ class DetectClassifyPipeline:
                 n = min(base, cap - lo)
                 if n <= 0:
                     break
-                cnt = torch.clamp(total - lo, min=0, max=n)            # device-side scalars: no host sync
+                pc = det.get("crop_part_counts")
+                if pc is not None and pc.numel() == k:
+                    cnt = pc[i:i + 1]                                   # device-side scalar written by yv_compact_crops_split
+                else:
+                    cnt = torch.clamp(total - lo, min=0, max=n)        # (another slicing than detect_stage prepared)
                 parts.append((lo, n, cnt, i, st))
                 lo += n
         cur = torch.cuda.current_stream()
@@ -140,15 +148,13 @@ class PipelinedRunner:
 
     def __init__(self, pipe: DetectClassifyPipeline, split_classifier=False, run_ahead: int = 1,
                  det_priority: int = -1, gemm_cus: Optional[int] = 208):
-        """gemm_cus: workgroups of the persistent classifier GEMMs (yv_set_option "linear_p8_cus", PROCESS-WIDE, set here and
-        left in place).  Those workgroups own a CU each for a whole launch (160 KB of LDS, 256 VGPRs x 8 waves), so with all
+        """gemm_cus: workgroups of the persistent classifier GEMMs (yv_set_option "linear_p8_cus": per thread, set around this
+        runner's own classifier submissions and restored afterwards).  Those workgroups own a CU each for a whole launch (160 KB of LDS, 256 VGPRs x 8 waves), so with all
         256 CUs taken the kernels of the other streams (detector, the other half-batch's LayerNorm / attention) can only
         start when a GEMM ends; leaving 48 CUs free lets them run alongside: 8.07 -> 7.75 ms per step measured (208 and 200
         equal, 224 7.85, 192 and below worse again).  None keeps the library default (every CU)."""
         self.pipe = pipe
-        if gemm_cus is not None:
-            from . import set_option
-            set_option("linear_p8_cus", int(gemm_cus))
+        self.gemm_cus = None if gemm_cus is None else int(gemm_cus)
         self.run_ahead = max(int(run_ahead), 1)                    # batches the detect stream may lead the classifier by
         self.s_det = torch.cuda.Stream(priority=det_priority)
         self.s_cls = torch.cuda.Stream()
@@ -157,6 +163,8 @@ class PipelinedRunner:
         if n_split >= 2 and HW_QUEUES < 8:
             n_split = 0          # with HIP's default 4 hardware queues the extra streams collide and the split is slower
         self.s_sub = [torch.cuda.Stream() for _ in range(n_split)] if n_split >= 2 else None
+        if n_split >= 2:
+            pipe.parts = n_split                                   # detect_stage publishes one crop count per classifier stream
         self._last = None
         self._done = []                                            # "classifier finished" events of the last two batches
 
@@ -182,7 +190,14 @@ class PipelinedRunner:
             ready.record(self.s_det)
         with torch.cuda.stream(self.s_cls):
             self.s_cls.wait_event(ready)
-            out = self.pipe.classify_stage(images if src_images is None else src_images, det, self.s_sub)
+            from . import get_option, set_option
+            prev = get_option("linear_p8_cus")
+            if self.gemm_cus is not None:
+                set_option("linear_p8_cus", self.gemm_cus)
+            try:
+                out = self.pipe.classify_stage(images if src_images is None else src_images, det, self.s_sub)
+            finally:
+                set_option("linear_p8_cus", prev)
             done = torch.cuda.Event()
             done.record(self.s_cls)
         out["done"] = done
