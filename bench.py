@@ -116,6 +116,13 @@ def bench_train(args, rank, world, dev, dist):
                           "config": {"workload": "ViT-B/16 fine-tune fwd+bwd, 224x224 (BASELINE.json configs[2])",
                                      "batch_per_gpu": R, "global_batch": R * world, "parallelism": f"dp{world}",
                                      "loss": float(loss[0])},
+                          # whole-step figure: model flops (3 x forward) over the step time, against the dense bf16 MFMA peak; the
+                          # per-kernel split is profiles/r03_train_vit_kernel_stats.csv (12 GEMMs per block of 22 GFLOP each at
+                          # 6,304 rows: forward on gemm_p9 / gemm_dma, data gradients on the transposed weight mirror, weight
+                          # gradients on gemm_tn)
+                          "roofline": {"bound": "mfma", "achieved": flop * args.steps / dt / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": flop * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                                       "kernel": "whole step (model flops / step time)"},
                           "model_tflops_per_gpu": flop * args.steps / dt / 1e12}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -159,6 +166,9 @@ def bench_train_yolo(args, rank, world, dev, dist):
                           "config": {"workload": "YOLOv8s(nc=80) train step, 640x640 (BASELINE.json configs[3])",
                                      "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                                      "boxes_per_image": G, "loss": [float(v) for v in loss.cpu()]},
+                          "roofline": {"bound": "mfma", "achieved": flop * args.steps / dt / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": flop * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                                       "kernel": "whole step (model flops / step time); per-kernel split: profiles/r03_train_yolo_kernel_stats.csv"},
                           "model_tflops_per_gpu": flop * args.steps / dt / 1e12}), flush=True)
     if dist is not None:
         dist.barrier()

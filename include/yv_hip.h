@@ -360,6 +360,13 @@ int yv_loss_fwd_bwd(const float* logits, const int32_t* labels, int B, int nc, f
 int yv_sgd_step(float* p, const float* g, float* m, size_t n, float lr, float momentum, float weight_decay,
                 float grad_scale, int first, void* bf16_mirror /* optional: bf16 copy of the updated p */, void* stream);
 
+/* Batched bf16 transpose dst[b] (cols, rows) = src[b] (rows, cols)^T; matrix b starts `*_stride` elements after matrix b-1.
+ * rows, cols multiples of 8, 16-byte aligned.  The trainer (autograd of every nn.Linear of timm's Block, reference loop
+ * utils/trainClass.py:403-407 `loss.backward()`) keeps a transposed bf16 mirror of the block weights so that the data
+ * gradient dX = dY . W runs as an ordinary yv_linear on W^T. */
+int yv_transpose_bf16_batched(const void* src, void* dst, int rows, int cols, int batch, long long src_stride,
+                              long long dst_stride, void* stream);
+
 /* Optimisers ultralytics builds for `optimizer='auto'` (the reference calls `.train(..., lr0=1e-4, lrf=1e-4)` with that
  * default, utils/trainYolo.py:33), element-wise in the operation order of torch's single-tensor implementations:
  * kind 1 = torch.optim.SGD(momentum=beta1, nesterov=True, weight_decay) (v unused), kind 2 = torch.optim.AdamW(betas,

@@ -118,8 +118,11 @@ def test_linear_exact_integer(yv, M, N, K, kind):
     (25216, 768, 768, "res", 0), (25216, 768, 3072, "res", 0), (12608, 768, 768, "res", 0), (6304, 2304, 768, "plain", 128),
     (6304, 768, 768, "res", 160), (6304, 2304, 768, "plain", 192), (6304, 3072, 768, "gelu", 224), (12608, 768, 3072, "res", 224),
     (5000, 256, 128, "f32", 160), (9999, 512, 192, "res", 128)])
-def test_linear_persistent_8phase_exact_integer(yv, M, N, K, kind, rows):
-    """gemm_p8_kernel (persistent 8-phase kernel: 128..256 x 256 tiles, LDS-DMA stream running across tile boundaries) forced
+@pytest.mark.parametrize("variant", [9, 11])
+def test_linear_persistent_8phase_exact_integer(yv, M, N, K, kind, rows, variant):
+    """variant 11 = gemm_p9_kernel (round 3: the free-running form - one barrier per K tile, stores straight from the accumulators
+    with the weight rows permuted on the DMA source side; tile heights 160 .. 256, so a forced 128 takes its default); variant 9 =
+    gemm_p8_kernel (persistent 8-phase kernel: 128..256 x 256 tiles, LDS-DMA stream running across tile boundaries) forced
     through yv_set_option("linear_variant", 9); `rows` forces the tile height (0 = the host's choice).  Exact integer operands:
     every wrong offset, stage parity (odd K-tile counts: K = 192, 320), cross-tile prefetch into the wrong tile, ragged last M
     tile (zeros through the buffer range check), dummy DMA slot of the narrow tiles or slab mix-up is a wrong integer.  Shapes
@@ -134,7 +137,7 @@ def test_linear_persistent_8phase_exact_integer(yv, M, N, K, kind, rows):
     flags = {"plain": 0, "gelu": yv.EPI_GELU, "res": yv.EPI_RES_F32, "f32": yv.EPI_OUT_F32}[kind]
     f32 = kind in ("res", "f32")
     x = torch.randint(-64, 65, (M, N), generator=g).float()
-    yv.set_option("linear_variant", 9)
+    yv.set_option("linear_variant", variant)
     yv.set_option("linear_p8_rows", rows)
     try:
         def run(m_dev=None, m_mul=1, with_bias=True):
@@ -199,6 +202,60 @@ def test_linear_persistent_8phase_race_screen(yv):
         torch.cuda.synchronize()
     finally:
         yv.set_option("linear_variant", 1); yv.set_option("linear_p8_cus", 0); yv.set_option("linear_p8_rows", 0)
+
+
+@pytest.mark.parametrize("M,N,K,rows", [(6304, 3072, 768, 0), (6304, 768, 3072, 0), (2048 + 37, 768, 256, 160), (6304, 768, 768, 192),
+                                       (9999, 512, 128, 224)])
+def test_linear_free_running_trainer_epilogues(yv, M, N, K, rows):
+    """The trainer's forms of yv_linear_ex on gemm_p9_kernel against the 128 x 128 kernel (same rounding steps: bit for bit):
+    f32 residual read from ANOTHER tensor (x_mid = x_in + ...), YV_EPI_SAVE_PRE (pre-activation kept next to the GELU output),
+    YV_EPI_GELU_BWD (data gradient of fc2 times gelu'(saved pre-activation))."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    xin = torch.randn(M, N, generator=g).to(DEV)
+    u = bf(torch.randn(M, N, generator=g)).to(DEV)
+
+    def run(p8, form):
+        yv.set_option("linear_p8", p8); yv.set_option("linear_p8_rows", rows if p8 else 0)
+        if form == "resf":
+            out = torch.full((M, N), 7.0, device=DEV)
+            yv.linear_ex(a, w, bias, out, flags=yv.EPI_RES_F32, res_f32=xin)
+            return (out,)
+        if form == "save_pre":
+            out = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=DEV); pre = torch.full((M, N), 5.0, dtype=torch.bfloat16, device=DEV)
+            yv.linear_ex(a, w, bias, out, flags=yv.EPI_GELU | yv.EPI_SAVE_PRE, aux=pre)
+            return out, pre
+        out = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=DEV)
+        yv.linear_ex(a, w, None, out, flags=yv.EPI_GELU_BWD, aux=u)
+        return (out,)
+    try:
+        for form in ("resf", "save_pre", "gelu_bwd"):
+            ref, got = run(0, form), run(3, form)
+            torch.cuda.synchronize()
+            for r, o in zip(ref, got):
+                assert torch.equal(r, o), (form, float((r.float() - o.float()).abs().max()))
+        # the reference itself against torch on the first form
+        out = run(3, "resf")[0]
+        assert rel_l2(out.cpu(), xin.cpu() + a.float().cpu() @ w.float().cpu().t() + bias.cpu()) < 1e-5
+    finally:
+        yv.set_option("linear_p8", 3); yv.set_option("linear_p8_rows", 0)
+
+
+def test_transpose_bf16_batched(yv):
+    g = torch.Generator().manual_seed(5)
+    src = bf(torch.randn(3 * 1000 + 64 * 3, generator=g)).to(DEV)          # three 24 x 40 matrices, 1064 elements apart (16-byte aligned)
+    dst = torch.zeros_like(src)
+    yv.transpose_bf16_batched(src, dst, 24, 40, 3, 1064, 1064)
+    torch.cuda.synchronize()
+    for b_ in range(3):
+        m = src[b_ * 1064: b_ * 1064 + 960].view(24, 40)
+        assert torch.equal(dst[b_ * 1064: b_ * 1064 + 960].view(40, 24), m.t())
+    big = bf(torch.randn(2304, 768, generator=g)).to(DEV)
+    out = torch.empty(768, 2304, dtype=torch.bfloat16, device=DEV)
+    yv.transpose_bf16_batched(big, out, 2304, 768)
+    assert torch.equal(out, big.t())
 
 
 def test_gelu_fast_form_accuracy(yv):

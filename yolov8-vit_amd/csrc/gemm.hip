@@ -1495,9 +1495,11 @@ int launch_p8(GemmArgs& g, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 template <int V> using ic = std::integral_constant<int, V>;
 
-template <int MF, bool F32OUT, int DIAG = 0 /* tools/gemm_lab.hip only: cycle sums into g.partial */>
+template <int MF, bool F32OUT, int DIAG = 0 /* tools/gemm_lab.hip only: cycle sums into g.partial */,
+          int EXT = 0 /* trainer epilogues of the bf16 output: 1 = YV_EPI_SAVE_PRE (fc1 forward), 2 = YV_EPI_GELU_BWD (fc2 data gradient) */>
 __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     constexpr int NF = 4, P = (MF + 1) / 2;
+    static_assert(EXT == 0 || (!F32OUT && MF <= 7), "aux epilogues: bf16 output, tiles of up to 224 rows (registers)");
     constexpr int MF0 = (MF + 1) / 2, MF1 = MF - MF0;          // DMA halves of the activation rows of a group (piece bookkeeping of p8)
     constexpr int RG = MF * 16, BM = 2 * RG;
     constexpr int A_BYTES = 256 * 128, STAGE = 2 * A_BYTES, BIAS0 = 2 * STAGE;
@@ -1533,6 +1535,11 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.a0, 0, (int)(((long long)(g.M - 1) * g.lda0 + g.K) * 2), 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (int)((long long)g.N * g.K * 2), 0x00020000);
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)(((long long)(M - 1) * g.ldo + g.N) * (F32OUT ? 4 : 2)), 0x00020000);
+    // f32 residual read from another tensor of the output's layout (trainer: x_mid = x_in + ...), else read-modify-write of `out`
+    const auto rsR = __builtin_amdgcn_make_buffer_rsrc(F32OUT && g.resf ? (void*)g.resf : g.out, 0,
+                                                       (int)(((long long)(M - 1) * g.ldo + g.N) * (F32OUT ? 4 : 2)), 0x00020000);
+    // bf16 side tensor of the trainer epilogues (EXT): pre-activation, written (SAVE_PRE) or read (GELU_BWD)
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(EXT ? (void*)g.aux : g.out, 0, (int)(((long long)(M - 1) * (EXT ? g.ldaux : g.ldo) + g.N) * 2), 0x00020000);
 
     const int wm = wave >> 2, wn = wave & 3;
     const int wrow_m = wm * RG, wrow_n = wn * 64;
@@ -1754,20 +1761,67 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
             float4 bv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) bv[i] = *(const float4*)(bl + i * 4);
+            if constexpr (EXT == 2) {
+                // out = bf16(acc + b) * gelu'(u), u = the pre-activation the forward saved (same rounding steps as the 128 x 128 kernel's
+                // epilogue); u of two row fragments is in flight together
 #pragma unroll
-            for (int j = 0; j < MF; ++j) {
-                const int m = m0 + wrow_m + j * 16 + fr;
-                uint32_t pk[8];
+                for (int j0 = 0; j0 < MF; j0 += 2) {
+                    u32x4 ur[2][2];
+                    uint32_t offx[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
-                    float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
-                    if (gelu) { v0 = gelu_f(v0); v1 = gelu_f(v1); v2 = gelu_f(v2); v3 = gelu_f(v3); }
-                    pk[2 * i] = pack_bf16x2(v0, v1); pk[2 * i + 1] = pack_bf16x2(v2, v3);
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int m = m0 + wrow_m + (j0 + jj) * 16 + fr;
+                        offx[jj] = (j0 + jj < MF && m < M) ? (uint32_t)((m * g.ldaux + n0 + wrow_n + fq * 16) * 2) : 0x80000000u;
+                        ur[jj][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, offx[jj], 0, 0);
+                        ur[jj][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, offx[jj] + 16, 0, 0);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        if (j0 + jj >= MF) continue;
+                        const int j = j0 + jj;
+                        const int m = m0 + wrow_m + j * 16 + fr;
+                        uint32_t pk[8];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t d01 = pack_bf16x2(acc[i][j][0] + bv[i].x, acc[i][j][1] + bv[i].y);
+                            const uint32_t d23 = pack_bf16x2(acc[i][j][2] + bv[i].z, acc[i][j][3] + bv[i].w);
+                            const uint32_t u01 = ur[jj][i >> 1][(i & 1) * 2], u23 = ur[jj][i >> 1][(i & 1) * 2 + 1];
+                            pk[2 * i] = pack_bf16x2(bf16_to_f32((uint16_t)(d01 & 0xffff)) * gelu_grad_f(bf16_to_f32((uint16_t)(u01 & 0xffff))),
+                                                    bf16_to_f32((uint16_t)(d01 >> 16)) * gelu_grad_f(bf16_to_f32((uint16_t)(u01 >> 16))));
+                            pk[2 * i + 1] = pack_bf16x2(bf16_to_f32((uint16_t)(d23 & 0xffff)) * gelu_grad_f(bf16_to_f32((uint16_t)(u23 & 0xffff))),
+                                                        bf16_to_f32((uint16_t)(d23 >> 16)) * gelu_grad_f(bf16_to_f32((uint16_t)(u23 >> 16))));
+                        }
+                        const uint32_t off = m < M ? (uint32_t)((m * g.ldo + n0 + wrow_n + fq * 16) * 2) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[0], pk[1], pk[2], pk[3]}, rsO, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[4], pk[5], pk[6], pk[7]}, rsO, off, 16, 0);
+                    }
                 }
-                const uint32_t off = m < M ? (uint32_t)((m * g.ldo + n0 + wrow_n + fq * 16) * 2) : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[0], pk[1], pk[2], pk[3]}, rsO, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[4], pk[5], pk[6], pk[7]}, rsO, off, 16, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const int m = m0 + wrow_m + j * 16 + fr;
+                    uint32_t pk[8];
+                    if constexpr (EXT == 1) {                     // the pre-activation, bf16 (the backward's gelu'(u) reads it)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            pk[2 * i] = pack_bf16x2(acc[i][j][0] + bv[i].x, acc[i][j][1] + bv[i].y);
+                            pk[2 * i + 1] = pack_bf16x2(acc[i][j][2] + bv[i].z, acc[i][j][3] + bv[i].w);
+                        }
+                        const uint32_t offx = m < M ? (uint32_t)((m * g.ldaux + n0 + wrow_n + fq * 16) * 2) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[0], pk[1], pk[2], pk[3]}, rsX, offx, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[4], pk[5], pk[6], pk[7]}, rsX, offx, 16, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
+                        float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                        if (gelu) { v0 = gelu_f(v0); v1 = gelu_f(v1); v2 = gelu_f(v2); v3 = gelu_f(v3); }
+                        pk[2 * i] = pack_bf16x2(v0, v1); pk[2 * i + 1] = pack_bf16x2(v2, v3);
+                    }
+                    const uint32_t off = m < M ? (uint32_t)((m * g.ldo + n0 + wrow_n + fq * 16) * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[0], pk[1], pk[2], pk[3]}, rsO, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[4], pk[5], pk[6], pk[7]}, rsO, off, 16, 0);
+                }
             }
         } else {
             const bool rmw = g.flags & YV_EPI_RES_F32;
@@ -1786,7 +1840,7 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
                     off[jj] = (j0 + jj < MF && m < M) ? (uint32_t)((m * g.ldo + n0 + wrow_n + fq * 4) * 4) : 0x80000000u;
                     if (rmw) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) xr[jj][i] = __builtin_amdgcn_raw_buffer_load_b128(rsO, off[jj] + i * 64, 0, 0);
+                        for (int i = 0; i < 4; ++i) xr[jj][i] = __builtin_amdgcn_raw_buffer_load_b128(rsR, off[jj] + i * 64, 0, 0);
                     }
                 }
 #pragma unroll
@@ -1830,13 +1884,13 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     }
 }
 
-template <int MF, bool F32OUT>
+template <int MF, bool F32OUT, int EXT = 0>
 int launch_p9_inst(GemmArgs& g, hipStream_t st, int n_cu) {
     constexpr int BM = 32 * MF;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = g.N / 256;
     const size_t lds = 2 * 65536 + 16384;
-    auto kern = gemm_p9_kernel<MF, F32OUT>;
+    auto kern = gemm_p9_kernel<MF, F32OUT, 0, EXT>;
     {   // the dynamic-LDS grant belongs to the device's copy of the kernel: once per device and instance
         static std::atomic<unsigned> granted[2] = {{0u}, {0u}};    // bit d: device d (up to 64 devices)
         int dev = 0;
@@ -1870,13 +1924,16 @@ int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0) {
     g.sched = g_opt_p8_sched;
     const bool f32out = g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32);
     const bool even_nk = ((g.K / BK) & 1) == 0;                    // odd-P instances (160 / 192 rows) walk K tiles in pairs
+    const int ext = (g.flags & YV_EPI_SAVE_PRE) ? 1 : (g.flags & YV_EPI_GELU_BWD) ? 2 : 0;
     int best = rows ? rows : g_opt_p8_rows;
+    if (ext && best > 224) best = 224;
     if (!best) {
         long long best_cost = -1;
         const int cand[4] = {256, 224, 192, 160};
         for (int c = 0; c < 4; ++c) {
             if (cand[c] <= 192 && !even_nk) continue;
             if (cand[c] > 192 && f32out && even_nk) continue;      // f32 outputs: the residual prefetch next to the accumulators spills above 192 rows
+            if (cand[c] > 224 && ext) continue;                     // trainer epilogues: up to 224 rows
             const long long tiles = (long long)((g.M + cand[c] - 1) / cand[c]) * (g.N / 256);
             const long long rounds = (tiles + n_cu - 1) / n_cu;
             const long long cost = rounds * (cand[c] + 16);
@@ -1884,6 +1941,16 @@ int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0) {
         }
     }
     if (best <= 192 && !even_nk) best = 224;
+    if (ext == 1) switch (best) {
+        case 192: return launch_p9_inst<6, false, 1>(g, st, n_cu);
+        case 160: return launch_p9_inst<5, false, 1>(g, st, n_cu);
+        default: return launch_p9_inst<7, false, 1>(g, st, n_cu);
+    }
+    if (ext == 2) switch (best) {
+        case 192: return launch_p9_inst<6, false, 2>(g, st, n_cu);
+        case 160: return launch_p9_inst<5, false, 2>(g, st, n_cu);
+        default: return launch_p9_inst<7, false, 2>(g, st, n_cu);
+    }
     switch (best) {
         case 224: return f32out ? launch_p9_inst<7, true>(g, st, n_cu) : launch_p9_inst<7, false>(g, st, n_cu);
         case 192: return f32out ? launch_p9_inst<6, true>(g, st, n_cu) : launch_p9_inst<6, false>(g, st, n_cu);
@@ -2234,13 +2301,23 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
         // Isolated, the 8-phase 256x256 kernel is 3-13 % faster on N >= 1536, but inside the pipeline (operands
         // cold in L2, GELU / residual epilogues) the interleaved end-to-end A/B measures it 1-2 % slower.
         // persistent 8-phase kernel: wide bf16-output linears (the qkv / fc1 shapes), see gemm_p8_kernel for its restrictions
+        // (the free-running kernel also takes the trainer's forms: a separate f32 residual source, YV_EPI_SAVE_PRE, YV_EPI_GELU_BWD)
+        const bool p9_train = g_opt_p8 >= 3 && !(flags & ~(YV_EPI_BIAS | YV_EPI_GELU | YV_EPI_RES_F32 | YV_EPI_SAVE_PRE | YV_EPI_GELU_BWD)) &&
+                              (!res_f32 || (flags & YV_EPI_RES_F32)) &&
+                              (!(flags & YV_EPI_SAVE_PRE) || (flags & YV_EPI_GELU)) && !((flags & YV_EPI_GELU_BWD) && (flags & (YV_EPI_GELU | YV_EPI_SAVE_PRE))) &&
+                              (!aux || ((long long)(M - 1) * ldaux + N) * 2 < 0x7fffffffLL) && (res_f32 || aux) && !((K / BK) & 1);
         const bool p8_ok = !(N & 255) && N <= 4096 && K >= 128 &&
-                           !(flags & ~(YV_EPI_BIAS | YV_EPI_GELU | YV_EPI_RES_F32 | YV_EPI_OUT_F32)) &&
-                           !((flags & YV_EPI_GELU) && (flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32))) && g.staged && !res_f32 && !aux &&
+                           (p9_train || (!(flags & ~(YV_EPI_BIAS | YV_EPI_GELU | YV_EPI_RES_F32 | YV_EPI_OUT_F32)) && !res_f32 && !aux)) &&
+                           !((flags & YV_EPI_GELU) && (flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32))) && g.staged &&
                            ((long long)(M - 1) * lda + K) * 2 < 0x7fffffffLL && (long long)N * K * 2 < 0x7fffffffLL &&
                            ((long long)(M - 1) * ldo + N) * 4 < 0x7fffffffLL && !(ldo & 7) && !(lda & 7);
         if (variant == 1 && g_opt_p8 && p8_ok && M >= 2048 && (N >= 1536 || g_opt_p8 >= 2)) variant = g_opt_p8 >= 3 ? 11 : 9;
         if ((variant == 9 || variant == 11) && !p8_ok) variant = 1;
+        if (variant == 9 && p9_train) variant = 1;                  // (those forms exist in the free-running kernel only)
+        // a persistent grid of 256-column tiles needs enough tiles for the chip: the trainer's 6,304 x 768 products are 120 tiles of
+        // 160 rows - fewer than half the CUs - and run faster as 300 tiles of 128 x 128 at two workgroups per CU (measured: the
+        // fine-tune step 9.65 -> 9.9 ms with them on the persistent kernel)
+        if (variant == 11 && g_opt_variant == 1 && (long long)((M + 159) / 160) * (N >> 8) < 192) variant = 1;
         // free-running form (round 3): f32 outputs have the registers for 160-row tiles only, whose three-phase K tiles are walked
         // in pairs (K / 64 even); the 8-phase kernel takes the rest
         if (variant == 11 && (flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32)) && ((K / BK) & 1)) variant = 9;

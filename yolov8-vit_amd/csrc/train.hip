@@ -122,6 +122,38 @@ __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ dst, con
         dst[i] = __fadd_rn(__fmul_rn(dst[i], a), __fmul_rn(b, src[i]));            // ModelEMA: v *= d; v += (1 - d) * model
 }
 
+// Batched bf16 transpose dst[b][c][r] = src[b][r][c] (64 x 64 tiles through LDS, 16-byte global accesses): the trainer keeps a
+// TRANSPOSED bf16 mirror of every block linear's weight, so that the data gradient dX = dY . W is an ordinary "NT" product
+// (out columns = the weight's input features) and runs on the persistent forward GEMM instead of the transposing-read kernel.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int rows,
+                                                            int cols, long long src_stride, long long dst_stride) {
+    __shared__ uint16_t tile[64][64 + 2];
+    const uint16_t* s = src + (long long)blockIdx.z * src_stride;
+    uint16_t* d = dst + (long long)blockIdx.z * dst_stride;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                // 64 rows x 8 chunks of 8 elements
+        const int idx = t + i * 256, r = idx >> 3, ch = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rows && c0 + ch * 8 < cols) v = *(const uint4*)(s + (long long)(r0 + r) * cols + c0 + ch * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[r][ch * 8 + e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = t + i * 256, c = idx >> 3, ch = idx & 7;  // output row c (a source column), 8 source rows per chunk
+        if (c0 + c < cols && r0 + ch * 8 < rows) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[ch * 8 + 2 * e][c] | ((uint32_t)tile[ch * 8 + 2 * e + 1][c] << 16);
+            *(uint4*)(d + (long long)(c0 + c) * rows + r0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int yv_optim_step(int kind, float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
@@ -170,5 +202,15 @@ extern "C" int yv_sgd_step(float* p, const float* g, float* m, size_t n, float l
     int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, n, lr, momentum,
                        weight_decay, grad_scale, first, (uint16_t*)bf16_mirror);
+    return yv_launch_status();
+}
+
+extern "C" int yv_transpose_bf16_batched(const void* src, void* dst, int rows, int cols, int batch, long long src_stride,
+                                 long long dst_stride, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || batch <= 0 || (rows & 7) || (cols & 7)) return YV_ERR_ARG;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || (src_stride & 7) || (dst_stride & 7)) return YV_ERR_ARG;
+    if (batch > 65535 || (rows + 63) / 64 > 65535) return YV_ERR_LIMIT;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)src, (uint16_t*)dst, rows, cols, src_stride, dst_stride);
     return yv_launch_status();
 }

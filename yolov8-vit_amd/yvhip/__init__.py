@@ -122,6 +122,7 @@ _SIGS = {
     "yv_head_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "yv_loss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "yv_sgd_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp, _vp]),
+    "yv_transpose_bf16_batched": (_i, [_vp, _vp, _i, _i, _i, C.c_longlong, C.c_longlong, _vp]),
 }
 
 
@@ -399,6 +400,14 @@ def sgd_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, momen
     _chk_dev(p, g, m, mirror)
     check(lib.yv_sgd_step(_p(p), _p(g), _p(m), p.numel(), float(lr), float(momentum), float(weight_decay),
                           float(grad_scale), 1 if first else 0, _p(mirror), _st()), "yv_sgd_step")
+
+
+def transpose_bf16_batched(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, batch: int = 1, src_stride: int = 0,
+                           dst_stride: int = 0):
+    """dst[b] (cols, rows) = src[b] (rows, cols)^T for b < batch; strides in elements between consecutive matrices."""
+    _chk_dev(src, dst)
+    check(lib.yv_transpose_bf16_batched(_p(src), _p(dst), rows, cols, batch, src_stride, dst_stride, _st()),
+          "yv_transpose_bf16_batched")
 
 
 # ------------------------------------------------------------- dense math

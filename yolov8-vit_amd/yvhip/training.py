@@ -21,7 +21,8 @@ import torch
 
 from . import (EPI_GELU, EPI_GELU_BWD, EPI_OUT_F32, EPI_POSEMB, EPI_RES_F32, EPI_SAVE_PRE, YvError, attention_bwd,
                attention_train, cast_colsum, cls_rows, colsum_bf16, head_bwd, layernorm, layernorm_bwd, lib,
-               linear, linear_ex, linear_nn, loss_fwd_bwd, require_gpu, sgd_step, token_reduce, wgrad, wrapper_head)
+               linear, linear_ex, linear_nn, loss_fwd_bwd, require_gpu, sgd_step, token_reduce, transpose_bf16_batched, wgrad,
+               wrapper_head)
 from .engines import vit_cfg
 
 
@@ -69,6 +70,16 @@ class VitTrainer:
         reg("model.head.weight", 1000, D)
         self.w_head_pad = torch.zeros((1024, D), dtype=torch.bfloat16, device=self.dev)   # dgrad reduces over 1024
         self.b_head_pad = z(1024)
+        # ---- TRANSPOSED bf16 mirror of the block linears (same offsets; (K, N) row-major): the data gradient dX = dY . W is then
+        # an ordinary linear on W^T and runs on the persistent forward GEMM (round 3; the transposing-read kernel on the master
+        # layout ran at 0.12 of the MFMA roof and was a quarter of the step).  Refreshed after every optimizer step by four
+        # batched transposes (one per linear of a block, batch = depth): 170 MB read + 170 MB written, ~1 % of a step.
+        self.P16T = torch.zeros(o, dtype=torch.bfloat16, device=self.dev)
+        self.blk_stride = (self.off["model.blocks.1.attn.qkv.weight"] - self.off["model.blocks.0.attn.qkv.weight"]) if self.L > 1 else 0
+        for i in range(1, self.L):
+            for w in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
+                if self.off[f"model.blocks.{i}.{w}"] - self.off[f"model.blocks.0.{w}"] != i * self.blk_stride:
+                    raise YvError("state dict: blocks are not laid out with one stride")
         self.P16.copy_(self.P)                               # initial cast (plumbing); afterwards the SGD kernel mirrors
         self.refresh_working_copies()
         self._bufs: Dict[int, dict] = {}
@@ -107,6 +118,17 @@ class VitTrainer:
         """Only the 1000 -> 1024 padded head copies need touching: everything else is a view of the mirror."""
         self.w_head_pad[:1000].copy_(self.gemm_w["model.head.weight"][2])
         self.b_head_pad[:1000].copy_(self.p("model.head.bias"))
+        for w in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
+            key = "model.blocks.0." + w
+            N, K = self.gemm_w[key][0], self.gemm_w[key][1]
+            o = self.off[key]
+            transpose_bf16_batched(self.P16[o:], self.P16T[o:], N, K, self.L, self.blk_stride, self.blk_stride)
+
+    def wt(self, key: str) -> torch.Tensor:
+        """W^T of a block linear, (K, N) row-major bf16 (view of the transposed mirror)."""
+        N, K = self.gemm_w[key][0], self.gemm_w[key][1]
+        o = self.off[key]
+        return self.P16T[o:o + N * K].view(K, N)
 
     # ---- buffers ----------------------------------------------------------------------------------
     def _buffers(self, R: int) -> dict:
@@ -218,17 +240,17 @@ class VitTrainer:
             dxb_fc2, dxb_proj, dwide, dqkv = S["dxb_fc2"][:M], S["dxb_proj"][:M], S["dwide"][:M], S["dqkv"][:M]
             # MLP branch
             cast_colsum(dx, dxb_fc2, self.g(k + "mlp.fc2.bias"), b["ws"])
-            linear_nn(dxb_fc2, Wm(k + "mlp.fc2.weight"), dwide, flags=EPI_GELU_BWD, aux=b["u"][i])
+            linear_ex(dxb_fc2, self.wt(k + "mlp.fc2.weight"), None, dwide, flags=EPI_GELU_BWD, aux=b["u"][i])
             colsum_bf16(dwide, self.g(k + "mlp.fc1.bias"), b["ws"])
-            linear_nn(dwide, Wm(k + "mlp.fc1.weight"), b["dnar"])
+            linear(dwide, self.wt(k + "mlp.fc1.weight"), None, b["dnar"])
             layernorm_bwd(xmid, D, self.p(k + "norm2.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm2.weight"), self.g(k + "norm2.bias"), b["ws"])
             # attention branch
             cast_colsum(dx, dxb_proj, self.g(k + "attn.proj.bias"), b["ws"])
-            linear_nn(dxb_proj, Wm(k + "attn.proj.weight"), b["dnar"])
+            linear(dxb_proj, self.wt(k + "attn.proj.weight"), None, b["dnar"])
             attention_bwd(b["qkv"][i], b["o"][i], b["dnar"], b["lse"][i], R, N, H, dqkv, b["delta"])
             colsum_bf16(dqkv, self.g(k + "attn.qkv.bias"), b["ws"])
-            linear_nn(dqkv, Wm(k + "attn.qkv.weight"), b["dnar"])
+            linear(dqkv, self.wt(k + "attn.qkv.weight"), None, b["dnar"])
             layernorm_bwd(xin, D, self.p(k + "norm1.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm1.weight"), self.g(k + "norm1.bias"), b["ws"])
             # the block's four weight gradients: nothing on the data-gradient chain needs them, so they run on the side
