@@ -196,6 +196,15 @@ int yv_detect_decode(const float* box0, const float* box1, const float* box2, co
                      const float* cls2, int cls_ld, int B, int size, int nc, float* boxes, float* scores,
                      void* stream);
 
+/* Fused Detect tail: the last 1 x 1 convolutions of both branches (ultralytics Detect cv2.i.2: 64 -> 4 x reg_max box logits,
+ * cv3.i.2: c3 -> nc class logits; TensorRT builder docs/YOLO_TensorRT_Technical.md:160-212) + yv_detect_decode, three scales in
+ * one launch; bit-identical to the unfused sequence.  feat_s (B*Hs*Ws, ld) bf16: box-branch features in channels 0..63, class
+ * branch features in 64..64+c3-1.  w2[s] (64,64) bf16, b2[s] (64) f32, w3[s] (16,c3) bf16 with rows >= nc zero, b3[s] (16) f32
+ * (host arrays of three device pointers).  c3 in {64,128,192}, nc <= 16; otherwise YV_ERR_LIMIT (use the unfused path). */
+int yv_detect_tail(const void* feat0, const void* feat1, const void* feat2, int ld, int c3, const void* const* w2,
+                   const float* const* b2, const void* const* w3, const float* const* b3, int B, int size, int nc,
+                   float* boxes, float* scores, void* stream);
+
 /* ------------------------------------------------------------ dense math */
 
 /* Operand view for the implicit-GEMM kernel: NHWC bf16 tensor slice.

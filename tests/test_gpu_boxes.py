@@ -436,3 +436,24 @@ def test_sgd_step_bit_exact(yv):
     pe2, me2 = ot.sgd_step(pe, gr2, me, 9.75528e-5)
     yv.sgd_step(pd, gr2.to(DEV), md, 9.75528e-5, first=False)
     assert torch.equal(pd.cpu(), pe2) and torch.equal(md.cpu(), me2)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,nc,S,B", [("n", 5, 640, 3), ("s", 5, 320, 2), ("m", 3, 128, 2), ("n", 16, 96, 1)])
+def test_fused_detect_tail_is_bit_identical(scale, nc, S, B):
+    """yv_detect_tail (last 1 x 1 convolutions of both Detect branches + DFL decode + sigmoid, three scales in one launch) against
+    the unfused sequence (two conv launches per scale into f32 logit buffers + yv_detect_decode): same accumulation order, same
+    decode statements -> the same bits, for c3 = 64 / 128 / 192 (YOLOv8 n / s / m), ragged last 16-pixel groups and nc up to 16."""
+    import yvhip
+    from yvhip import engines
+    yvhip.require_gpu()
+    eng = engines.YoloEngine(engines.init_yolo_state(scale, nc, seed=3, head_gain=4.0), scale, nc, S, "cuda:0")
+    assert eng.fused_tail
+    g = torch.Generator().manual_seed(S + nc)
+    img = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8).to("cuda:0")
+    boxes_f, scores_f = eng(img)
+    eng.fused_tail = False
+    boxes_u, scores_u = eng(img)
+    torch.cuda.synchronize()
+    assert torch.equal(boxes_f, boxes_u)
+    assert torch.equal(scores_f, scores_u)
+    assert float(scores_f.max()) > 0.3 and float(boxes_f.abs().max()) > 10          # a non-trivial head

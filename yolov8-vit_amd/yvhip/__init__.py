@@ -77,6 +77,7 @@ _SIGS = {
     "yv_augment_patchify": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "yv_mosaic_augment": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "yv_detect_tail": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "yv_optim_step": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "yv_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
     "yv_axpby": (_i, [_vp, _vp, _sz, _f, _f, _vp]),
@@ -380,6 +381,22 @@ def detect_decode(box_logits, cls_logits, size: int, nc: int):
     check(lib.yv_detect_decode(_p(box_logits[0]), _p(box_logits[1]), _p(box_logits[2]), _p(cls_logits[0]),
                                _p(cls_logits[1]), _p(cls_logits[2]), ld, B, size, nc, _p(boxes), _p(scores), _st()),
           "yv_detect_decode")
+    return boxes, scores
+
+
+def detect_tail(feats, c3: int, w2, b2, w3, b3, size: int, nc: int):
+    """Fused Detect tail: feats 3 x (B,Hs,Ws,ld) bf16 (box-branch features in channels 0..63, class-branch features behind them);
+    w2 3 x (64,64) bf16, b2 3 x (64) f32, w3 3 x (16,c3) bf16 (rows >= nc zero), b3 3 x (16) f32 -> boxes (B,A,4), scores (B,A,nc),
+    bit-identical to the two 1 x 1 convolutions + detect_decode."""
+    _chk_dev(*feats, *w2, *b2, *w3, *b3)
+    B, ld = feats[0].shape[0], feats[0].shape[-1]
+    A = sum((size // s) ** 2 for s in (8, 16, 32))
+    dev = feats[0].device
+    boxes = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, A, nc), dtype=torch.float32, device=dev)
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    check(lib.yv_detect_tail(_p(feats[0]), _p(feats[1]), _p(feats[2]), ld, c3, arr(w2), arr(b2), arr(w3), arr(b3), B, size, nc,
+                             _p(boxes), _p(scores), _st()), "yv_detect_tail")
     return boxes, scores
 
 

@@ -21,7 +21,7 @@ import torch
 from .guard import StepGuard
 from . import (EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, attention_mxfp8,
                cls_rows,
-               conv2d, detect_decode, layernorm, layernorm_mxfp8, linear, linear_mxfp8, linear_mxfp8_q, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
+               conv2d, detect_decode, detect_tail, layernorm, layernorm_mxfp8, linear, linear_mxfp8, linear_mxfp8_q, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
                wrapper_head)
 
 # --------------------------------------------------------------------------------------- YOLOv8
@@ -153,6 +153,14 @@ class YoloEngine:
             bp = torch.zeros(self.ncp, dtype=torch.float32, device=self.dev)
             bp[:nc] = self.b[kc]
             self.w[kc + ".pad"], self.b[kc + ".pad"] = wp, bp
+            wp16 = torch.zeros(16, self.c3, dtype=torch.bfloat16, device=self.dev)     # operand of the fused tail: one MFMA row fragment
+            bp16 = torch.zeros(16, dtype=torch.float32, device=self.dev)
+            if nc <= 16:
+                wp16[:nc] = self.w[kc]
+                bp16[:nc] = self.b[kc]
+            self.w[kc + ".pad16"], self.b[kc + ".pad16"] = wp16, bp16
+        # fused Detect tail (yv_detect_tail: last 1 x 1 convolutions + DFL decode + sigmoid in one launch, bit-identical)
+        self.fused_tail = self.c2 == 64 and nc <= 16 and self.c3 in (64, 128, 192)
         self._bufs: Dict[int, dict] = {}
         self.guard = StepGuard()                 # one replay of the launch list at a time (callers may be threads)
         self.A = sum((size // s) ** 2 for s in (8, 16, 32))
@@ -216,7 +224,8 @@ class YoloEngine:
                 return res
             return tuple([t.clone() for t in part] for part in res)
 
-    def _forward_raw(self, images: torch.Tensor):
+    def _forward_raw(self, images: torch.Tensor, tail: bool = True):
+        """tail=False: stop in front of the last 1 x 1 convolutions and return the per-scale feature buffers (B,Hs,Ws,c2+c3)."""
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3:
             raise YvError("images must be (B,S,S,3) uint8")
         B, S = images.shape[0], images.shape[1]
@@ -261,6 +270,9 @@ class YoloEngine:
             conv2d(view(hb, 0, c2), None, B, hs, hs, 3, 1, self.w[k], self.b[k], hc, 0, EPI_SILU)
             k = f"model.22.cv3.{s}.1.conv"
             conv2d(view(hb, c2, c3), None, B, hs, hs, 3, 1, self.w[k], self.b[k], hc, c2, EPI_SILU)
+            if not tail:
+                box_l.append(hc)
+                continue
             k = f"model.22.cv2.{s}.2"
             conv2d(view(hc, 0, c2), None, B, hs, hs, 1, 1, self.w[k], self.b[k], bufs[f"det{s}.box"], 0, EPI_OUT_F32)
             k = f"model.22.cv3.{s}.2.pad"
@@ -271,6 +283,12 @@ class YoloEngine:
 
     def __call__(self, images: torch.Tensor):
         with self.guard:                         # the decode reads the engine-owned head buffers
+            if self.fused_tail:
+                feats, _ = self._forward_raw(images, tail=False)
+                return detect_tail(feats, self.c3,
+                                   [self.w[f"model.22.cv2.{s}.2"] for s in range(3)], [self.b[f"model.22.cv2.{s}.2"] for s in range(3)],
+                                   [self.w[f"model.22.cv3.{s}.2.pad16"] for s in range(3)],
+                                   [self.b[f"model.22.cv3.{s}.2.pad16"] for s in range(3)], self.size, self.nc)
             box_l, cls_l = self._forward_raw(images)
             return detect_decode(box_l, cls_l, self.size, self.nc)
 
