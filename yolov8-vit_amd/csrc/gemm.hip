@@ -802,6 +802,167 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmArgs g) {
 
 
 // ---------------------------------------------------------------------------------------------
+// Convolution on the LDS-DMA GEMM structure (round 3): the implicit-GEMM gather of igemm_kernel expressed as the per-lane offset of
+// a `buffer_load ... lds`.  For layers whose input channels are a multiple of 64 a K step lies inside ONE 3 x 3 tap and ONE source,
+// so everything that changes along K - the tap's pixel displacement, the channel base, the source of a two-source 1 x 1 - is
+// wave-uniform and travels in the instruction's scalar offset; what a lane contributes is fixed for the whole tile: the byte
+// offset of its output pixel's centre (+ its swizzled 16-byte chunk) and nine tap-validity bits (padding -> an out-of-range
+// offset -> zeros through the descriptor's range check).  No staging registers, no address arithmetic in the loop, no LDS stores:
+// the K step is the linear kernel's (two LDS stages, DMA of step k+1 under the MFMAs of step k).  igemm_kernel was bound by the
+// VALU issue of exactly that gather and staging.  Epilogues: finish_tile (bias, SiLU, bf16 shortcut, f32 output).
+// Eligibility (host): (c0 + c1) % 64 == 0, c1 == 0 or (1 x 1 and c0 % 64 == 0), Cout >= 64, staged epilogue usable.
+// ---------------------------------------------------------------------------------------------
+template <int BN, int WM, int WN, int ST = 2 /* LDS stages: ST - 1 K steps of DMA in flight */>
+__global__ __launch_bounds__(256) void cgemm_dma_kernel(GemmArgs g) {
+    constexpr int BM = 128, NW = 4;
+    static_assert(WM * WN == NW, "four waves");
+    constexpr int MF = BM / WM / 16, NF = BN / WN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
+    constexpr int A_INS = BM / (8 * NW), W_INS = BN / (8 * NW);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = g.M;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= M) return;
+
+    const int lrow = lane >> 3, lch = lane & 7;
+    constexpr uint32_t OOB = 0x80000000u;
+    uint32_t a_off0[A_INS], a_off1[A_INS], a_taps[A_INS], w_off[W_INS];
+    const int hw = g.Hout * g.Wout;
+#pragma unroll
+    for (int j = 0; j < A_INS; ++j) {
+        const int r = (j * NW + wave) * 8 + lrow;
+        const int m = m0 + r;
+        const int mc = m < M ? m : M - 1;
+        const int b = mc / hw, rem = mc - b * hw;
+        const int oy = rem / g.Wout;
+        const int cy = oy * g.stride, cx = (rem - oy * g.Wout) * g.stride;
+        const uint32_t sw = (uint32_t)((lch ^ (r & 7)) << 4);
+        a_off0[j] = (uint32_t)((((long long)b * (g.Hin >> g.up0) + (cy >> g.up0)) * (g.Win >> g.up0) + (cx >> g.up0)) * g.lda0 * 2) + sw;
+        a_off1[j] = g.c1 ? (uint32_t)((((long long)b * (g.Hin >> g.up1) + (cy >> g.up1)) * (g.Win >> g.up1) + (cx >> g.up1)) * g.lda1 * 2) + sw : 0u;
+        uint32_t taps = 0;
+        if (m < M) {
+            if (g.ksize == 3) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+                    taps |= (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) ? (1u << t) : 0u;
+                }
+            } else {
+                taps = 1u;
+            }
+        }
+        a_taps[j] = taps;
+    }
+#pragma unroll
+    for (int j = 0; j < W_INS; ++j) {
+        const int r = (j * NW + wave) * 8 + lrow;
+        int n = n0 + r;
+        n = n < g.N ? n : g.N - 1;
+        w_off[j] = (uint32_t)(((long long)n * g.K + ((lch ^ (r & 7)) << 3)) * 2);
+    }
+    // the scalar offset is unsigned: source 0's descriptor starts one row + one pixel before the tensor (3 x 3 only)
+    const uint32_t bias0 = g.ksize == 3 ? (uint32_t)((g.Win + 1) * g.lda0 * 2) : 0u;
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.a0 - bias0), 0, 0x7fffffff, 0x00020000);
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(g.c1 ? g.a1 : g.a0), 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, 0x7fffffff, 0x00020000);
+    const int Cin = g.c0 + g.c1;
+    const int pad = g.ksize >> 1;
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        unsigned char* A = smem + buf * (A_BYTES + W_BYTES);
+        unsigned char* W = A + A_BYTES;
+        const int kb = kt * BK;                                  // (uniform)
+        if (g.c1 && kb >= g.c0) {                                // second source of a two-source 1 x 1
+            const int so = (kb - g.c0) * 2;
+#pragma unroll
+            for (int j = 0; j < A_INS; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(A + (j * NW + wave) * 1024), 16,
+                                                         (int)((a_taps[j] & 1u) ? a_off1[j] : OOB), so, 0, 0);
+        } else {
+            int tap = 0;
+            uint32_t so = bias0 + (uint32_t)(kb * 2);
+            if (g.ksize == 3) {
+                tap = g.cin_shift >= 0 ? (kb >> g.cin_shift) : kb / Cin;
+                const int cin = kb - tap * Cin;
+                const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), kx = tap - ky * 3;
+                so = bias0 + (uint32_t)((((ky - pad) * g.Win + (kx - pad)) * g.lda0 + cin) * 2);
+            }
+#pragma unroll
+            for (int j = 0; j < A_INS; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(A + (j * NW + wave) * 1024), 16,
+                                                         (int)(((a_taps[j] >> tap) & 1u) ? a_off0[j] : OOB), (int)so, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < W_INS; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(W + (j * NW + wave) * 1024), 16, (int)w_off[j], kb * 2, 0, 0);
+    };
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int wrow_m = wm * (BM / WM), wrow_n = wn * (BN / WN);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = g.K / BK;
+    // ring of ST stages, ST - 1 K steps in flight: the launches are latency-bound (9 .. 36 K steps per tile, one L2 / HBM round trip
+    // each when only the next step is in flight), and inside the pipeline the detector runs on the few CUs the classifier leaves
+    // free, where a tile's latency is all that counts.  Step kt: counted wait (the ST - 2 younger steps stay in flight), ONE raw
+    // barrier (step kt visible to every wave; every wave is done with step kt-1, whose stage the next issue refills), issue, MFMAs.
+    constexpr int INS = A_INS + W_INS;
+    int issued = 0;
+#pragma unroll
+    for (int p = 0; p < ST - 1; ++p)
+        if (p < nk) { issue(p, p); ++issued; }
+    int slot = 0, islot = (ST - 1) % ST;
+    for (int kt = 0; kt < nk; ++kt) {
+        // steps issued so far: `issued` (all of them once the prologue / earlier iterations ran out of steps)
+        if (issued - kt - 1 >= ST - 2 && ST > 2) {
+            if constexpr (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(INS) : "memory");
+            else if constexpr (ST == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * INS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (issued < nk) { issue(issued, islot); ++issued; islot = islot + 1 == ST ? 0 : islot + 1; }
+        const unsigned char* A = smem + slot * (A_BYTES + W_BYTES);
+        const unsigned char* W = A + A_BYTES;
+        slot = slot + 1 == ST ? 0 : slot + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[MF], fw[NF];
+            const int kc = ks * 4 + fq;
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int rr = wrow_m + j * 16 + fr;
+                fa[j] = *(const bf16x8*)(A + rr * 128 + ((kc ^ (rr & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int rr = wrow_n + i * 16 + fr;
+                fw[i] = *(const bf16x8*)(W + rr * 128 + ((kc ^ (rr & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_barrier" ::: "memory");                       // the staged epilogue reuses the tile buffers
+    finish_tile<MF, NF>(g, acc, M, m0, n0, wrow_m, wrow_n, lane, wave, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
 // MXFP8 variant of the LDS-DMA GEMM (BASELINE.json configs[4]: FP8 classifier GEMMs).  Operands are OCP e4m3 bytes
 // with one E8M0 scale per 32 consecutive K elements of a row (the OCP "MX" block format); the block-scaled
 // v_mfma_scale_f32_16x16x128_f8f6f4 applies both scales in hardware and runs at twice the bf16 MFMA rate.  A 128-byte LDS
@@ -2124,8 +2285,43 @@ bool epi_can_stage(const GemmArgs& g) {
     return true;
 }
 
+int g_opt_conv_dma = 2;             // convolutions with 64-aligned input channels on the LDS-DMA structure ("conv_dma": 0 off, 1..4 see dispatch)
+
+template <int BN, int WM, int WN, int ST>
+int launch_cdma(GemmArgs& g, hipStream_t st) {
+    g.tiles_m = (g.M + 127) / 128;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const size_t lds = ST * (size_t)(128 + BN) * 128;
+    auto kern = cgemm_dma_kernel<BN, WM, WN, ST>;
+    if (lds > 65536) {
+        static std::atomic<unsigned> granted[2] = {{0u}, {0u}};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return YV_ERR_LAUNCH;
+        if (!((granted[dev >> 5].load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return YV_ERR_LAUNCH;
+            granted[dev >> 5].fetch_or(1u << (dev & 31), std::memory_order_release);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, st, g);
+    return yv_launch_status();
+}
+
 template <int MODE>
 int dispatch(GemmArgs& g, hipStream_t st) {
+    if constexpr (MODE == 1) {
+        const int Cin = g.c0 + g.c1;
+        if (g_opt_conv_dma && g.N >= 64 && (Cin % 64) == 0 && (g.c1 == 0 || (g.ksize == 1 && (g.c0 % 64) == 0)) && g.staged &&
+            g.splitk <= 1 && !g.m_dev && (g.K % BK) == 0)
+        {
+            // conv_dma: 1 = two stages (128-wide tiles for Cout > 64), 2 = three stages, 64-wide tiles (two workgroups per CU, four K
+            // steps in flight per CU), 3 = three stages, 128-wide tiles (one workgroup per CU), 4 = four stages, 64-wide tiles
+            if (g_opt_conv_dma == 2) return launch_cdma<64, 4, 1, 3>(g, st);
+            if (g_opt_conv_dma == 3) return g.N > 64 ? launch_cdma<128, 2, 2, 3>(g, st) : launch_cdma<64, 4, 1, 3>(g, st);
+            if (g_opt_conv_dma == 4) return launch_cdma<64, 4, 1, 4>(g, st);
+            return g.N > 64 ? launch_cdma<128, 2, 2, 2>(g, st) : launch_cdma<64, 4, 1, 2>(g, st);
+        }
+    }
     if (g.N > 64) return launch<MODE, 128, 128, 2, 2>(g, st);
     if (g.N > 32) return launch<MODE, 128, 64, 4, 1>(g, st);
     if (g.N > 16) return launch<MODE, 128, 32, 4, 1>(g, st);
@@ -2242,6 +2438,7 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!strcmp(key, "linear_p8_sched")) { g_opt_p8_sched = value; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { g_opt_splitk = value; return YV_OK; }
     if (!strcmp(key, "linear_splitk")) { g_opt_linear_splitk = value; return YV_OK; }
+    if (!strcmp(key, "conv_dma")) { g_opt_conv_dma = value; return YV_OK; }
     return YV_ERR_ARG;
 }
 
@@ -2257,6 +2454,7 @@ extern "C" int yv_get_option(const char* key, int* value) {
     if (!strcmp(key, "linear_p8_sched")) { *value = g_opt_p8_sched; return YV_OK; }
     if (!strcmp(key, "conv_splitk")) { *value = g_opt_splitk; return YV_OK; }
     if (!strcmp(key, "linear_splitk")) { *value = g_opt_linear_splitk; return YV_OK; }
+    if (!strcmp(key, "conv_dma")) { *value = g_opt_conv_dma; return YV_OK; }
     return YV_ERR_ARG;
 }
 

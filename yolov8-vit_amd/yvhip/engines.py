@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from .guard import StepGuard
-from . import (EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, attention_mxfp8,
+from . import (set_option, EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, attention_mxfp8,
                cls_rows,
                conv2d, detect_decode, detect_tail, layernorm, layernorm_mxfp8, linear, linear_mxfp8, linear_mxfp8_q, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
                wrapper_head)
@@ -392,6 +392,9 @@ class VitEngine:
             raise YvError("fc.3.weight does not match num_classes")
         self._bufs: Dict[tuple, dict] = {}
         self._guards: Dict[int, StepGuard] = {}
+        # PipelinedRunner: first block whose persistent GEMMs take every CU again (the reduced budget exists for the detector of the
+        # NEXT batch, which runs beside the first part of a classifier pass only); None = one budget for the whole pass
+        self.full_cus_from: Optional[int] = None
 
     def guard(self, slot: int = 0) -> StepGuard:
         """Guard of one buffer set: hold it across backbone() + head() (the features live in engine-owned buffers).
@@ -441,7 +444,9 @@ class VitEngine:
         rows = cap * N
         if self.dtype == "mxfp8":
             return self._backbone_mxfp8(b, cap, count)
-        for blk in self.blocks:
+        for i, blk in enumerate(self.blocks):
+            if self.full_cus_from is not None and i == self.full_cus_from:
+                set_option("linear_p8_cus", 0)          # the caller (PipelinedRunner) restores its own setting after the pass
             layernorm(x, blk["n1w"], blk["n1b"], h, rows, D, D, D, count_dev=count, rows_per_count=N)
             linear(h, blk["wqkv"], blk["bqkv"], qkv, m_dev=count, m_mul=N)
             attention(qkv, cap, N, H, o, r_dev=count)

@@ -147,7 +147,7 @@ class PipelinedRunner:
     unlucky pair vs 8.61 ms with the priority split; a lucky pair gives the same 8.6-8.9 ms)."""
 
     def __init__(self, pipe: DetectClassifyPipeline, split_classifier=False, run_ahead: int = 1,
-                 det_priority: int = -1, gemm_cus: Optional[int] = 208):
+                 det_priority: int = -1, gemm_cus: Optional[int] = 208, full_cus_from: Optional[int] = None):
         """gemm_cus: workgroups of the persistent classifier GEMMs (yv_set_option "linear_p8_cus": per thread, set around this
         runner's own classifier submissions and restored afterwards).  Those workgroups own a CU each for a whole launch (160 KB of LDS, 256 VGPRs x 8 waves), so with all
         256 CUs taken the kernels of the other streams (detector, the other half-batch's LayerNorm / attention) can only
@@ -155,6 +155,7 @@ class PipelinedRunner:
         equal, 224 7.85, 192 and below worse again).  None keeps the library default (every CU)."""
         self.pipe = pipe
         self.gemm_cus = None if gemm_cus is None else int(gemm_cus)
+        self.full_cus_from = full_cus_from                         # transformer block from which the GEMMs take every CU again
         self.run_ahead = max(int(run_ahead), 1)                    # batches the detect stream may lead the classifier by
         self.s_det = torch.cuda.Stream(priority=det_priority)
         self.s_cls = torch.cuda.Stream()
@@ -194,6 +195,8 @@ class PipelinedRunner:
             prev = get_option("linear_p8_cus")
             if self.gemm_cus is not None:
                 set_option("linear_p8_cus", self.gemm_cus)
+            for v in self.pipe.vits:
+                v.full_cus_from = self.full_cus_from
             try:
                 out = self.pipe.classify_stage(images if src_images is None else src_images, det, self.s_sub)
             finally:
