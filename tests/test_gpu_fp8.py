@@ -81,7 +81,10 @@ def test_quant_mxfp8_matches_emulation(yv, rows, K):
 
 
 @pytest.mark.parametrize("M,N,K,kind", [(256, 256, 256, "f32"), (1000, 384, 1024, "f32"), (197 * 4, 1024, 1024, "bf16_bias"),
-                                        (640, 512, 4096, "gelu"), (130, 128, 128, "res")])
+                                        (640, 512, 4096, "gelu"), (130, 128, 128, "res"),
+                                        # persistent free-running MX kernel (gemm_p9_kernel<..., MX>: M >= 2048, N % 256 == 0, >= 192 tiles)
+                                        (6304 + 37, 3072, 1024, "gelu"), (12608, 1024, 1024, "res"), (5000, 4096, 256, "f32"),
+                                        (6304, 2304, 768, "bf16_bias"), (9999, 1024, 2048, "res")])
 def test_linear_mxfp8_matches_dequantised_product(yv, M, N, K, kind):
     g = torch.Generator().manual_seed(M + N + K)
     a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(torch.bfloat16)
@@ -183,6 +186,34 @@ def test_linear_mxfp8_q_equals_linear_then_quant(yv):
     torch.cuda.synchronize()
     assert torch.equal(q[:300], q_ref[:300]) and torch.equal(s[:, :300], s_ref[:, :300])
     assert float(q[300:].float().abs().sum()) == 0
+
+
+def test_linear_mxfp8_q_persistent_equals_linear_then_quant(yv):
+    """The same hand-off on the persistent MX kernel (ViT-L fc1 shape at 32 crops): byte-identical to the bf16-output GEMM of the
+    same kernel followed by yv_quant_mxfp8, and to the 128 x 128 kernel's image (linear_p8 = 0)."""
+    g = torch.Generator().manual_seed(13)
+    M, N, K = 6304 + 19, 4096, 1024
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    aq, asc = yv.quant_mxfp8(a)
+    wq, wsc = yv.quant_mxfp8(w)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    yv.linear_mxfp8(aq, asc, wq, wsc, bias, out, flags=yv.EPI_GELU)
+    q_ref, s_ref = yv.quant_mxfp8(out)
+    q = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+    s = torch.zeros_like(s_ref)
+    yv.linear_mxfp8_q(aq, asc, wq, wsc, bias, q, s, flags=yv.EPI_GELU)
+    torch.cuda.synchronize()
+    assert torch.equal(q, q_ref) and torch.equal(s[:, :M], s_ref[:, :M])
+    try:
+        yv.set_option("linear_p8", 0)
+        out0 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        yv.linear_mxfp8(aq, asc, wq, wsc, bias, out0, flags=yv.EPI_GELU)
+        torch.cuda.synchronize()
+        assert torch.equal(out0, out)
+    finally:
+        yv.set_option("linear_p8", 3)
 
 
 def test_pipeline_with_mxfp8_classifier(yv):

@@ -91,6 +91,10 @@ struct GemmArgs {
     long long ldmxq;
     uint8_t* mxs;                // ... and its E8M0 block scales, K-step-major (N/128, mx_rows, 4)
     long long mx_rows;
+    // gemm_p9_kernel<MX>: E8M0 scales of the fp8 operands, K-step-major (K/128, rows, 4) (a0 / w then point at e4m3 bytes, lda0 in bytes)
+    const uint8_t* mx_sa;
+    const uint8_t* mx_sw;
+    long long mx_rows_a, mx_rows_w;
 };
 
 // x * sigmoid(x) through the hardware reciprocal (1 ulp) instead of an IEEE division: the division's scale / fixup sequence was
@@ -1657,13 +1661,20 @@ int launch_p8(GemmArgs& g, hipStream_t st) {
 template <int V> using ic = std::integral_constant<int, V>;
 
 template <int MF, bool F32OUT, int DIAG = 0 /* tools/gemm_lab.hip only: cycle sums into g.partial */,
-          int EXT = 0 /* trainer epilogues of the bf16 output: 1 = YV_EPI_SAVE_PRE (fc1 forward), 2 = YV_EPI_GELU_BWD (fc2 data gradient) */>
+          int EXT = 0 /* trainer epilogues of the bf16 output: 1 = YV_EPI_SAVE_PRE (fc1 forward), 2 = YV_EPI_GELU_BWD (fc2 data gradient) */,
+          bool MX = false /* OCP MXFP8 operands (e4m3 bytes + one E8M0 scale per 32 K): a 128-byte LDS row is 128 K elements = ONE
+                             block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) per fragment pair and K tile; same DMA, LDS images,
+                             fragment reads and schedule, twice the flops per K tile; the two 1 KB scale rows of a K tile travel with
+                             its activation / weight pieces (issued by waves 0 / 1) */>
 __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     constexpr int NF = 4, P = (MF + 1) / 2;
+    static_assert(!MX || EXT == 0, "MX: no trainer epilogues");
     static_assert(EXT == 0 || (!F32OUT && MF <= 7), "aux epilogues: bf16 output, tiles of up to 224 rows (registers)");
     constexpr int MF0 = (MF + 1) / 2, MF1 = MF - MF0;          // DMA halves of the activation rows of a group (piece bookkeeping of p8)
     constexpr int RG = MF * 16, BM = 2 * RG;
-    constexpr int A_BYTES = 256 * 128, STAGE = 2 * A_BYTES, BIAS0 = 2 * STAGE;
+    constexpr int A_BYTES = 256 * 128, SC0 = 2 * A_BYTES, STAGE = 2 * A_BYTES + (MX ? 2048 : 0), BIAS0 = 2 * STAGE;
+    constexpr int ESZ = MX ? 1 : 2;                               // bytes per operand element; K elements per 128-byte row: 128 / ESZ
+    constexpr int KT = 128 / ESZ;
     constexpr bool PERM = !F32OUT;
     static_assert(MF >= 5 && MF <= 8, "tile heights 160..256");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1693,8 +1704,13 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
         float* bl = (float*)(smem + BIAS0);
         for (int i = tid; i < g.N; i += 512) bl[i] = (g.flags & YV_EPI_BIAS) ? g.bias[i] : 0.0f;
     }
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.a0, 0, (int)(((long long)(g.M - 1) * g.lda0 + g.K) * 2), 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (int)((long long)g.N * g.K * 2), 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.a0, 0, (int)(((long long)(g.M - 1) * g.lda0 + g.K) * ESZ), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (int)((long long)g.N * g.K * ESZ), 0x00020000);
+    const int nk_all = g.K / KT;
+    const auto rsSA = __builtin_amdgcn_make_buffer_rsrc((void*)(MX ? (const void*)g.mx_sa : (const void*)g.a0), 0,
+                                                        MX ? (int)((long long)nk_all * g.mx_rows_a * 4) : 16, 0x00020000);
+    const auto rsSW = __builtin_amdgcn_make_buffer_rsrc((void*)(MX ? (const void*)g.mx_sw : (const void*)g.w), 0,
+                                                        MX ? (int)((long long)nk_all * g.mx_rows_w * 4) : 16, 0x00020000);
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)(((long long)(M - 1) * g.ldo + g.N) * (F32OUT ? 4 : 2)), 0x00020000);
     // f32 residual read from another tensor of the output's layout (trainer: x_mid = x_in + ...), else read-modify-write of `out`
     const auto rsR = __builtin_amdgcn_make_buffer_rsrc(F32OUT && g.resf ? (void*)g.resf : g.out, 0,
@@ -1732,7 +1748,7 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
             for (int h = 0; h < 2; ++h) {
                 const int r0 = a_piece_row(h, s_);
                 const int ra = r0 + lrow, m = m0 + ra;
-                o[h][j] = (valid && r0 >= 0 && m < g.M) ? (uint32_t)(((long long)m * g.lda0 + ((lch ^ (ra & 7)) << 3)) * 2) : 0x80000000u;
+                o[h][j] = (valid && r0 >= 0 && m < g.M) ? (uint32_t)((long long)m * g.lda0 * ESZ + ((lch ^ (ra & 7)) << 4)) : 0x80000000u;
             }
         }
     };
@@ -1745,7 +1761,7 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
             const int rw = (rh >> 5) * 64 + h * 32 + (rh & 31);          // LDS row of the W tile
             // PERM: LDS row (block b, fragment i, row r) holds weight row b * 64 + (r >> 2) * 16 + i * 4 + (r & 3)
             const int rsrc = PERM ? ((rw & ~63) | (((rw & 15) >> 2) << 4) | (((rw >> 4) & 3) << 2) | (rw & 3)) : rw;
-            ow[h][j] = (uint32_t)((rsrc * g.K + ((lch ^ (rw & 7)) << 3)) * 2);
+            ow[h][j] = (uint32_t)(rsrc * g.K * ESZ + ((lch ^ (rw & 7)) << 4));
         }
     }
     auto lds_dst = [&](int kind, int j) __attribute__((always_inline)) -> int {
@@ -1758,28 +1774,42 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
         return A_BYTES + ((rb >> 5) * 64 + (kind - 2) * 32 + (rb & 31)) * 128;
     };
 
-    const int nk = g.K / BK;
+    const int nk = g.K / KT;
+    int sa_row0 = 0;                                             // MX: first activation row of the tile the `oa` offsets point at
     uint32_t oa[2][2];
     int seq = seq0 + lid, m0, n0, m0n = 0, n0n = 0;
     coords(seq, m0, n0);
     set_a_offsets(oa, m0, true);
+    sa_row0 = m0;
     bool has_next = seq + Lx < seq1;
     if (has_next) coords(seq + Lx, m0n, n0n);
     int gk = 0;                                                // K tiles consumed so far (stage of a K tile = parity)
 
     // piece `kind` (0, 1 activation halves; 2, 3 weight halves) of K tile k of the tile whose column origin is nb
+    // MX: the K tile's 256 activation-row scale dwords (wave 0, with activation half 0) / weight-row scale dwords (wave 1, with weight
+    // half 0): 1 KB each = one wave instruction; rows past the scale array read zeros (those rows are never stored)
     auto issue_a = [&](int kind, int k, int st) __attribute__((always_inline)) {
         unsigned char* base = smem + (st & 1) * STAGE;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t)(base + lds_dst(kind, j)), 16, (int)oa[kind][j], k * 128, 0, 0);
+        if constexpr (MX) {
+            if (kind == 0 && wave == 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsSA, (lds_void_t)(base + SC0), 16, lane * 16,
+                                                         (int)(((long long)k * g.mx_rows_a + sa_row0) * 4), 0, 0);
+        }
     };
     auto issue_w = [&](int kind, int k, int st, int nb) __attribute__((always_inline)) {
         unsigned char* base = smem + (st & 1) * STAGE;
-        const int so = nb * g.K * 2 + k * 128;
+        const int so = nb * g.K * ESZ + k * 128;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t)(base + lds_dst(kind, j)), 16, (int)ow[kind - 2][j], so, 0, 0);
+        if constexpr (MX) {
+            if (kind == 2 && wave == 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsSW, (lds_void_t)(base + SC0 + 1024), 16, lane * 16,
+                                                         (int)(((long long)k * g.mx_rows_w + nb) * 4), 0, 0);
+        }
     };
     // K tile t + d (d in {1, 2}) of this tile or, past its end, of the next tile
     auto issue_rel = [&](int kind, int t, int d, auto tail_c) __attribute__((always_inline)) {
@@ -1793,32 +1823,63 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     f32x4 acc[NF][MF];
     bf16x8 fa[2][2][2];                                         // [ring half][row fragment of the pair][k step]
     bf16x8 fw[4][2];                                            // [column fragment][k step] of the current K tile
+    // MX: a fragment is the 8-register operand of the 128-deep MFMA (chunks fq and 4 + fq of the row), built where it is read
+    i32x8 fa8[2][2], fw8[4];
+    int sca[2][2], scw[4];                                       // this lane's block scale (byte 0) per row fragment
     auto read_pair = [&](auto half_c, const unsigned char* A, int pr) __attribute__((always_inline)) {
         constexpr int HALF = decltype(half_c)::value;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             if (2 * pr + jj >= MF) continue;
             const int rr = wrow_m + (2 * pr + jj) * 16 + fr;
+            if constexpr (MX) {
+                const u32x4 lo = *(const u32x4*)(A + rr * 128 + ((fq ^ (rr & 7)) << 4));
+                const u32x4 hi = *(const u32x4*)(A + rr * 128 + (((4 + fq) ^ (rr & 7)) << 4));
+                fa8[HALF][jj] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                sca[HALF][jj] = (int)(*(const uint32_t*)(A + SC0 + rr * 4) >> (8 * fq));
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[HALF][jj][ks] = *(const bf16x8*)(A + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+                for (int ks = 0; ks < 2; ++ks) fa[HALF][jj][ks] = *(const bf16x8*)(A + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+            }
         }
     };
-    auto read_w = [&](const unsigned char* W, int ks) __attribute__((always_inline)) {
+    auto read_w = [&](const unsigned char* W, int ks) __attribute__((always_inline)) {   // W = stage base + A_BYTES
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rr = wrow_n + i * 16 + fr;
-            fw[i][ks] = *(const bf16x8*)(W + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+            if constexpr (MX) {
+                if (ks == 0) {
+                    const u32x4 lo = *(const u32x4*)(W + rr * 128 + ((fq ^ (rr & 7)) << 4));
+                    const u32x4 hi = *(const u32x4*)(W + rr * 128 + (((4 + fq) ^ (rr & 7)) << 4));
+                    fw8[i] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                    // LDS row rr holds weight row (rr & ~63) | ((rr & 15) >> 2) << 4 | ((rr >> 4) & 3) << 2 | (rr & 3) when PERM
+                    const int rs_ = PERM ? ((rr & ~63) | (((rr & 15) >> 2) << 4) | (((rr >> 4) & 3) << 2) | (rr & 3)) : rr;
+                    scw[i] = (int)(*(const uint32_t*)(W + (SC0 - A_BYTES) + 1024 + rs_ * 4) >> (8 * fq));
+                }
+            } else {
+                fw[i][ks] = *(const bf16x8*)(W + rr * 128 + (((ks * 4 + fq) ^ (rr & 7)) << 4));
+            }
         }
     };
     auto mma = [&](auto half_c, int pr, int ks) __attribute__((always_inline)) {
         constexpr int HALF = decltype(half_c)::value;
+        if constexpr (MX) { if (ks == 0) return; }                // one 128-deep MFMA per fragment pair: issued in the second slot
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 if (2 * pr + jj >= MF) continue;
-                acc[i][2 * pr + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][ks], fa[HALF][jj][ks], acc[i][2 * pr + jj], 0, 0, 0);
+                if constexpr (MX) {
+                    // inline asm: around the builtin hipcc's register allocation needs ~100 more VGPRs (every instance spilled 120-360
+                    // registers into the K loop; with bf16 MFMAs in its place none did).  Operands come from LDS reads (waited for by
+                    // the compiler, which sees them as inputs) and a shift issued a phase earlier: no hazard window inside the string
+                    // beyond the s_nop; the accumulator chains MFMA -> MFMA (no wait states) and is next read in the epilogue.
+                    asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+                                 : "+v"(acc[i][2 * pr + jj]) : "v"(fw8[i]), "v"(fa8[HALF][jj]), "v"(scw[i]), "v"(sca[HALF][jj]));
+                } else {
+                    acc[i][2 * pr + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][ks], fa[HALF][jj][ks], acc[i][2 * pr + jj], 0, 0, 0);
+                }
             }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -1835,7 +1896,7 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     // one K tile.  PAR: ring half that holds row pair 0 of this K tile (odd P: alternates).  LASTK: t = nk - 1
     auto ktile = [&](int t, auto tail_c, auto par_c) __attribute__((always_inline)) {
         constexpr int TAIL = decltype(tail_c)::value, PAR = decltype(par_c)::value;
-        if constexpr (TAIL == 1) set_a_offsets(oa, m0n, has_next);                 // from here on activation pieces belong to the next tile
+        if constexpr (TAIL == 1) { set_a_offsets(oa, m0n, has_next); sa_row0 = m0n; }   // from here on activation pieces belong to the next tile
         const unsigned char* A = smem + (gk & 1) * STAGE;
         const unsigned char* An = smem + ((gk + 1) & 1) * STAGE;
         auto phase = [&](auto p_c) __attribute__((always_inline)) {
@@ -1845,14 +1906,15 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
             else if constexpr (TAIL != 2) read_pair(ic<NXT>{}, An, 0);          // row pair 0 of the next K tile
             dma_for_phase(p, t, tail_c);
             mma(ic<CUR>{}, p, 0);
-            if constexpr (p == P - 1 && TAIL != 2) {
+            if constexpr (p == P - 1 && TAIL != 2 && !MX) {
                 __builtin_amdgcn_sched_barrier(0);
                 read_w(An + A_BYTES, 0);                                        // in place: k step 0 of K tile t had its last use
             }
             mma(ic<CUR>{}, p, 1);
             if constexpr (p == P - 1 && TAIL != 2) {
                 __builtin_amdgcn_sched_barrier(0);
-                read_w(An + A_BYTES, 1);
+                if constexpr (MX) read_w(An + A_BYTES, 0);                      // (MX: both halves feed the one MFMA of a fragment pair)
+                else read_w(An + A_BYTES, 1);
             }
             if constexpr (p == P - 2) {
                 // sync point: every DMA issued so far (all of K tile t+1) has landed, this wave's fragment reads are retired;
@@ -1957,6 +2019,49 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
                         __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[4], pk[5], pk[6], pk[7]}, rsO, off, 16, 0);
                     }
                 }
+            } else if (MX && (g.flags & YV_EPI_OUT_MXFP8)) {
+                // the consumer is another MXFP8 GEMM (fc1 -> fc2): the lane's 16 consecutive (bf16-rounded) outputs + the 16 of lane ^ 16
+                // are one 32-column MX block; same arithmetic as the 128 x 128 kernel's epilogue (byte-identical images)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const int m = m0 + wrow_m + j * 16 + fr;
+                    float f[16], amax = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
+                        float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                        if (gelu) { v0 = gelu_f(v0); v1 = gelu_f(v1); v2 = gelu_f(v2); v3 = gelu_f(v3); }
+                        f[4 * i] = bf16_to_f32(f32_to_bf16(v0)); f[4 * i + 1] = bf16_to_f32(f32_to_bf16(v1));
+                        f[4 * i + 2] = bf16_to_f32(f32_to_bf16(v2)); f[4 * i + 3] = bf16_to_f32(f32_to_bf16(v3));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) amax = fmaxf(amax, fabsf(f[q]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+                    int e = -127;
+                    if (amax > 0.f) {
+                        int ex;
+                        const float mant = frexpf(amax * (1.0f / 448.0f), &ex);
+                        e = mant == 0.5f ? ex - 1 : ex;
+                        e = e < -127 ? -127 : (e > 127 ? 127 : e);
+                    }
+                    const float inv = ldexpf(1.0f, -e);
+                    uint32_t q4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int pq = 0;
+                        pq = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * i] * inv, f[4 * i + 1] * inv, pq, false);
+                        pq = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * i + 2] * inv, f[4 * i + 3] * inv, pq, true);
+                        q4[i] = (uint32_t)pq;
+                    }
+                    if (m < M) {
+                        const int n = n0 + wrow_n + fq * 16;
+                        *(uint4*)(g.mxq + (long long)m * g.ldmxq + n) = make_uint4(q4[0], q4[1], q4[2], q4[3]);
+                        if (!(fq & 1)) {
+                            const int bk = n >> 5;
+                            g.mxs[((long long)(bk >> 2) * g.mx_rows + m) * 4 + (bk & 3)] = (uint8_t)(e + 127);
+                        }
+                    }
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < MF; ++j) {
@@ -2045,13 +2150,13 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     }
 }
 
-template <int MF, bool F32OUT, int EXT = 0>
+template <int MF, bool F32OUT, int EXT = 0, bool MX = false>
 int launch_p9_inst(GemmArgs& g, hipStream_t st, int n_cu) {
     constexpr int BM = 32 * MF;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = g.N / 256;
-    const size_t lds = 2 * 65536 + 16384;
-    auto kern = gemm_p9_kernel<MF, F32OUT, 0, EXT>;
+    const size_t lds = 2 * 65536 + 16384 + (MX ? 4096 : 0);
+    auto kern = gemm_p9_kernel<MF, F32OUT, 0, EXT, MX>;
     {   // the dynamic-LDS grant belongs to the device's copy of the kernel: once per device and instance
         static std::atomic<unsigned> granted[2] = {{0u}, {0u}};    // bit d: device d (up to 64 devices)
         int dev = 0;
@@ -2074,7 +2179,7 @@ int launch_p9_inst(GemmArgs& g, hipStream_t st, int n_cu) {
 }
 
 // rows: 0 = choose (minimise rounds x (rows + per-tile cost)), else 160 / 192 / 224 / 256
-int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0) {
+int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0, bool mx = false) {
     static int n_cu_dev = 0;
     if (!n_cu_dev) {
         int dev = 0; hipDeviceProp_t prop;
@@ -2084,7 +2189,7 @@ int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0) {
     const int n_cu = (g_opt_p8_cus > 0 && g_opt_p8_cus < n_cu_dev) ? g_opt_p8_cus : n_cu_dev;
     g.sched = g_opt_p8_sched;
     const bool f32out = g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32);
-    const bool even_nk = ((g.K / BK) & 1) == 0;                    // odd-P instances (160 / 192 rows) walk K tiles in pairs
+    const bool even_nk = ((g.K / (mx ? 128 : BK)) & 1) == 0;         // odd-P instances (160 / 192 rows) walk K tiles in pairs
     const int ext = (g.flags & YV_EPI_SAVE_PRE) ? 1 : (g.flags & YV_EPI_GELU_BWD) ? 2 : 0;
     int best = rows ? rows : g_opt_p8_rows;
     if (ext && best > 224) best = 224;
@@ -2095,6 +2200,7 @@ int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0) {
             if (cand[c] <= 192 && !even_nk) continue;
             if (cand[c] > 192 && f32out && even_nk) continue;      // f32 outputs: the residual prefetch next to the accumulators spills above 192 rows
             if (cand[c] > 224 && ext) continue;                     // trainer epilogues: up to 224 rows
+            if (cand[c] > 160 && mx && f32out) continue;            // MX with f32 output: 160 rows (registers)
             const long long tiles = (long long)((g.M + cand[c] - 1) / cand[c]) * (g.N / 256);
             const long long rounds = (tiles + n_cu - 1) / n_cu;
             const long long cost = rounds * (cand[c] + 16);
@@ -2102,6 +2208,12 @@ int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0) {
         }
     }
     if (best <= 192 && !even_nk) best = 224;
+    if (mx) switch (best) {
+        case 224: return f32out ? launch_p9_inst<7, true, 0, true>(g, st, n_cu) : launch_p9_inst<7, false, 0, true>(g, st, n_cu);
+        case 192: return f32out ? launch_p9_inst<6, true, 0, true>(g, st, n_cu) : launch_p9_inst<6, false, 0, true>(g, st, n_cu);
+        case 160: return f32out ? launch_p9_inst<5, true, 0, true>(g, st, n_cu) : launch_p9_inst<5, false, 0, true>(g, st, n_cu);
+        default: return f32out ? launch_p9_inst<8, true, 0, true>(g, st, n_cu) : launch_p9_inst<8, false, 0, true>(g, st, n_cu);
+    }
     if (ext == 1) switch (best) {
         case 192: return launch_p9_inst<6, false, 1>(g, st, n_cu);
         case 160: return launch_p9_inst<5, false, 1>(g, st, n_cu);
@@ -2400,6 +2512,19 @@ static int linear_mx_impl(const void* Aq, long long lda, const void* Ascale, lon
     g.group_m = g_opt_group_m > 0 ? g_opt_group_m : 8;
     a.sa = (const uint8_t*)Ascale; a.sw = (const uint8_t*)Wscale; a.rows_a = a_rows_pad; a.rows_w = w_rows_pad;
     g.mxq = (uint8_t*)out_q; g.ldmxq = ldq; g.mxs = (uint8_t*)out_scales; g.mx_rows = out_rows_pad;
+    // persistent free-running kernel (round 3): the bf16 schedule with one block-scaled MFMA per fragment pair and K tile
+    g.mx_sa = a.sa; g.mx_sw = a.sw; g.mx_rows_a = a.rows_a; g.mx_rows_w = a.rows_w;
+    {
+        const int nkm = K >> 7;
+        const bool f32o = flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32);
+        if (g_opt_p8 >= 3 && g_opt_variant == 1 && !(N & 255) && N <= 4096 && nkm >= 2 && M >= 2048 &&
+            !((flags & YV_EPI_GELU) && f32o) && !((flags & YV_EPI_OUT_MXFP8) && f32o) && !(f32o && (nkm & 1)) &&
+            (long long)((M + 159) / 160) * (N >> 8) >= 192 &&
+            (long long)(M - 1) * lda + K < 0x7fffffffLL && (long long)N * K < 0x7fffffffLL &&
+            ((long long)(M - 1) * ldo + N) * 4 < 0x7fffffffLL && (long long)(K >> 7) * a.rows_a * 4 < 0x7fffffffLL &&
+            (long long)(K >> 7) * a.rows_w * 4 < 0x7fffffffLL)
+            return launch_p9(g, (hipStream_t)stream, 0, true);
+    }
     // (a 256 x 128 / 8-wave instance of the same template was measured on the ViT-L shapes: 4-15 % slower than two
     // 128 x 128 workgroups per CU, like its bf16 counterpart, and is not dispatched)
     g.tiles_m = (M + 127) / 128; g.tiles_n = (N + 127) / 128;
