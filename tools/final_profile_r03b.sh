@@ -1,0 +1,15 @@
+# round 3, part B (GPU box): training profiles, detector stage, isolated kernels
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03f
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+bash $R/tools/train_profile.sh r03f/train > $O/train_profile.log 2>&1; echo "train done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/det -- python3 $R/tools/detect_only.py > $O/det.log 2> $O/det.err; echo "det done"
+python3 $R/tools/stage_split.py > $O/stage_split.txt 2>&1; echo "stage done"
+python3 $R/tools/conv_layers.py > $O/conv_layers.txt 2>&1; echo "conv done"
+timeout -k 10 300 $R/tools/build/gemm_lab > $O/gemm_lab.txt 2>&1; echo "lab done"
+python3 $R/tools/attn_ablate.py > $O/attn_ablate.txt 2>&1; ATTN_R=64 python3 $R/tools/attn_ablate.py >> $O/attn_ablate.txt 2>&1; echo "attn done"
+bash $R/tools/attn_pmc.sh r03f/attn_pmc > $O/attn_pmc.log 2>&1; echo "attn pmc done"
+bash $R/tools/traffic_by_instance.sh r03f/traffic > $O/traffic_by_instance.txt 2>&1; echo "traffic done"
+python3 $R/tools/fp8_bench.py > $O/fp8_bench.txt 2>&1; echo "fp8 done"
+python3 $R/tools/cus_sweep.py > $O/cus_sweep.txt 2>&1; echo "cus done"

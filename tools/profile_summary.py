@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 outputs (gpurun_out/<dir>) into the tracked summaries under profiles/.
 usage: profile_summary.py <round-tag> <stats_dir> [<fetch_pmc_dir> <write_pmc_dir>] [--kernel PATTERN]
-PATTERN (default gemm_p8_kernel) selects the dominant kernel's rows (all template instances together)."""
+PATTERN (default gemm_p9_kernel) selects the dominant kernel's rows (all template instances together)."""
 import csv, glob, json, os, sys
 
 argv = list(sys.argv[1:])
-pat = "gemm_p8_kernel"
+pat = "gemm_p9_kernel"
 if "--kernel" in argv:
     i = argv.index("--kernel"); pat = argv[i + 1]; del argv[i:i + 2]
 tag, stats_dir = argv[0], argv[1]
