@@ -315,6 +315,7 @@ typedef const __attribute__((address_space(1))) void* at_gptr_t;
 typedef __attribute__((address_space(3))) void* at_lptr_t;
 typedef __attribute__((ext_vector_type(4))) short at_s16x4;
 typedef __attribute__((address_space(3))) at_s16x4* at_lds_s16x4_t;
+typedef float at_f32x2 __attribute__((ext_vector_type(2)));
 
 // transposing reads of PV step n (inline asm: see the kernel) and the counted wait for them
 template <int N_>
@@ -456,15 +457,23 @@ __global__ __launch_bounds__(NT * 64) void attention_pipe_kernel(const uint16_t*
         }
         mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
         const float mb = mxv * scale_log2e;
-        float l0 = 0.f, l1 = 0.f;
+        // packed fp32 for the scale and the row sums (v_pk_fma_f32 / v_pk_add_f32: half the vector instructions; two waves share a
+        // SIMD's vector pipe here and it is the pipe this kernel is bound by - tools/valu_rate.hip)
+        at_f32x2 l2 = {0.f, 0.f};
+        const at_f32x2 sc2 = {scale_log2e, scale_log2e}, nmb2 = {-mb, -mb};
         bf16x8 fp[NT][2];
         auto expg = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kt][e], scale_log2e, -mb));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kt][e + 1], scale_log2e, -mb));
-                l0 += p0; l1 += p1;
-                fp[kt][e >> 3][e & 7] = (__bf16)p0; fp[kt][e >> 3][(e & 7) + 1] = (__bf16)p1;
+                // elements e .. e + 3 of every lane are keys >= 32 kt + 8 (e >> 2): past N (last group only) they are exactly 0
+                if (kt == NT - 1 && kt * 32 + 8 * (e >> 2) >= N) {
+                    fp[kt][e >> 3][e & 7] = (__bf16)0.f; fp[kt][e >> 3][(e & 7) + 1] = (__bf16)0.f;
+                    continue;
+                }
+                const at_f32x2 x = __builtin_elementwise_fma(at_f32x2{s[kt][e], s[kt][e + 1]}, sc2, nmb2);
+                const at_f32x2 pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                l2 += pp;
+                fp[kt][e >> 3][e & 7] = (__bf16)pp[0]; fp[kt][e >> 3][(e & 7) + 1] = (__bf16)pp[1];
             }
         };
         f32x16 o[2];
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(NT * 64) void attention_pipe_kernel(const uint16_t*
         pv_group(std::integral_constant<int, 0>{}); pv_group(std::integral_constant<int, 1>{}); pv_group(std::integral_constant<int, 2>{});
         pv_group(std::integral_constant<int, 3>{}); pv_group(std::integral_constant<int, 4>{}); pv_group(std::integral_constant<int, 5>{});
         pv_group(std::integral_constant<int, 6>{});
-        const float l = (l0 + l1) + __shfl_xor(l0 + l1, 32, 64);
+        const float l = (l2[0] + l2[1]) + __shfl_xor(l2[0] + l2[1], 32, 64);
         // ---- normalise and store -------------------------------------------------------------------
         const int r = item / H, hd = item - r * H;
         const int q = wave * 32 + rl;
