@@ -117,11 +117,14 @@ def test_linear_exact_integer(yv, M, N, K, kind):
     (2048 + 37, 1536, 128, "plain", 256), (70000, 256, 192, "plain", 0), (12608, 4096, 1024, "gelu", 0), (300, 512, 64 * 5, "plain", 256),
     (25216, 768, 768, "res", 0), (25216, 768, 3072, "res", 0), (12608, 768, 768, "res", 0), (6304, 2304, 768, "plain", 128),
     (6304, 768, 768, "res", 160), (6304, 2304, 768, "plain", 192), (6304, 3072, 768, "gelu", 224), (12608, 768, 3072, "res", 224),
-    (5000, 256, 128, "f32", 160), (9999, 512, 192, "res", 128)])
+    (5000, 256, 128, "f32", 160), (9999, 512, 192, "res", 128),
+    (6304, 768, 768, "res", 96), (6304, 768, 3072, "plain", 96), (9999, 512, 192, "res", 96), (5000, 256, 128, "f32", 96),
+    (300, 512, 64 * 5, "plain", 128), (70000, 256, 192, "gelu", 96), (6304, 768, 2304, "plain", 0)])
 @pytest.mark.parametrize("variant", [9, 11])
 def test_linear_persistent_8phase_exact_integer(yv, M, N, K, kind, rows, variant):
     """variant 11 = gemm_p9_kernel (round 3: the free-running form - one barrier per K tile, stores straight from the accumulators
-    with the weight rows permuted on the DMA source side; tile heights 160 .. 256, so a forced 128 takes its default); variant 9 =
+    with the weight rows permuted on the DMA source side; tile heights 96 .. 256 - the 96 / 128-row forms have two phases per K tile
+    and fetch a whole K tile in one of them); variant 9 =
     gemm_p8_kernel (persistent 8-phase kernel: 128..256 x 256 tiles, LDS-DMA stream running across tile boundaries) forced
     through yv_set_option("linear_variant", 9); `rows` forces the tile height (0 = the host's choice).  Exact integer operands:
     every wrong offset, stage parity (odd K-tile counts: K = 192, 320), cross-tile prefetch into the wrong tile, ragged last M

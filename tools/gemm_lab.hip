@@ -179,6 +179,11 @@ int main(int argc, char** argv) {
     printf("device %s, %d CUs, M = %d\n", prop.name, n_cu, M);
     std::vector<Problem> ps = {make_problem("qkv", M, 2304, 768, 0), make_problem("proj", M, 768, 768, YV_EPI_RES_F32),
                                make_problem("fc1", M, 3072, 768, YV_EPI_GELU), make_problem("fc2", M, 768, 3072, YV_EPI_RES_F32)};
+    if (getenv("LAB_TRAIN")) {                                  // the trainer's data-gradient products with 768 outputs (bf16)
+        ps.push_back(make_problem("dqkv", M, 768, 2304, 0));
+        ps.push_back(make_problem("dfc1", M, 768, 3072, 0));
+        ps.push_back(make_problem("dproj", M, 768, 768, 0));
+    }
     std::vector<Variant> vs;
     vs.push_back({"p8 (shipped)", [](GemmArgs& g, hipStream_t st) { return launch_p8(g, st); }});
     if (getenv("LAB_R1")) vs.push_back({"dma128 (round 1)", [](GemmArgs& g, hipStream_t st) { return launch_dma<128, 128, 2, 2>(g, st); }});
@@ -187,6 +192,8 @@ int main(int argc, char** argv) {
     vs.push_back({"p9 224", [](GemmArgs& g, hipStream_t st) { return launch_p9(g, st, 224); }});
     vs.push_back({"p9 192", [](GemmArgs& g, hipStream_t st) { return launch_p9(g, st, 192); }});
     vs.push_back({"p9 160", [](GemmArgs& g, hipStream_t st) { return launch_p9(g, st, 160); }});
+    vs.push_back({"p9 128", [](GemmArgs& g, hipStream_t st) { return launch_p9(g, st, 128); }});
+    vs.push_back({"p9 96", [](GemmArgs& g, hipStream_t st) { return launch_p9(g, st, 96); }});
     double tot_fl = 0; std::vector<double> tot_us(vs.size(), 0.0);
     for (auto& p : ps) {
         // reference = shipped kernel
@@ -216,7 +223,7 @@ int main(int argc, char** argv) {
     }
     for (size_t v = 0; v < vs.size(); ++v)
         printf("LAYER %-24s %7.1f us  flop-weighted frac %.3f\n", vs[v].name.c_str(), tot_us[v], tot_fl / tot_us[v] / 1e6 / 2500.0);
-    if (!getenv("LAB_NO_DIAG")) {
+    if (!getenv("LAB_NO_DIAG") && !getenv("LAB_TRAIN")) {
         run_diag9<7, false>(ps[0], n_cu);
         run_diag9<5, true>(ps[1], n_cu);
         run_diag9<8, false>(ps[2], n_cu);

@@ -29,6 +29,9 @@
 namespace {
 
 constexpr int BK = 64;            // bf16 elements per K step
+int g_opt_p9_small = 1;              // gemm_p9_kernel: 128 / 96-row tiles allowed ("linear_p9_small")
+int g_opt_p9_small_fixed = 48;       // ... and the fixed part of their cost per K tile, in rows ("linear_p9_small_fixed")
+int g_opt_wgrad_split = 0;           // > 0: forced number of token slices of a matrix-shaped weight gradient (tools/wgrad_bench.py)
 int g_opt_wgrad_cap = 128;          // token slices of a conv-shaped weight gradient (few output tiles, 10^5+ rows)
 thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;   // yv_set_launch_timing: next gemm_dma launch
 int g_opt_variant = 1;            // 1 = auto; tuning knobs (yv_set_option): linear kernel variant, M-group size, persistent grid
@@ -1612,7 +1615,7 @@ int launch_p8(GemmArgs& g, hipStream_t st) {
     // tile height: minimise rounds x (rows + a fixed per-tile cost worth ~24 rows: epilogue, pipeline turn-around)
     int best = 256;
     if (g_opt_p8_rows) {
-        best = g_opt_p8_rows;
+        best = g_opt_p8_rows < 128 ? 128 : g_opt_p8_rows;          // (96: a tile height of the free-running kernel only)
         if ((g.flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32)) && best > 192) best = 192;
     } else {
         long long best_cost = -1;
@@ -1676,7 +1679,8 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     constexpr int ESZ = MX ? 1 : 2;                               // bytes per operand element; K elements per 128-byte row: 128 / ESZ
     constexpr int KT = 128 / ESZ;
     constexpr bool PERM = !F32OUT;
-    static_assert(MF >= 5 && MF <= 8, "tile heights 160..256");
+    static_assert(MF >= 3 && MF <= 8, "tile heights 96..256");
+    static_assert(MF >= 5 || (!MX && EXT == 0), "96 / 128-row tiles: plain bf16 operands only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -1889,6 +1893,12 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     // of K tile t+2, the first phases of the next K tile the weight halves of (its) K tile t+1; phase P-2 - the one that ends in
     // the next sync point - issues nothing, so the youngest piece has a whole phase to land before it is waited for
     auto dma_for_phase = [&](int p, int t, auto tail_c) __attribute__((always_inline)) {
+        if constexpr (P == 2) {
+            // 96 / 128-row tiles: the phase that follows the sync point is also the only one that does not end in the next: all eight
+            // pieces of K tile t+2 go here (its stage - K tile t's - is free: the weight fragments of K tile t were read a K tile ago)
+            if (p == 1) { issue_rel(0, t, 2, tail_c); issue_rel(1, t, 2, tail_c); issue_rel(2, t, 2, tail_c); issue_rel(3, t, 2, tail_c); }
+            return;
+        }
         if (p == P - 1) { issue_rel(0, t, 2, tail_c); issue_rel(1, t, 2, tail_c); return; }
         if constexpr (P == 4) { if (p < 2) issue_rel(2 + p, t, 1, tail_c); }
         else { if (p == 0) { issue_rel(2, t, 1, tail_c); issue_rel(3, t, 1, tail_c); } }
@@ -1951,7 +1961,10 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     // ---- first tile: K tile 0 complete, the activation halves of K tile 1 in flight ---------------------------------------
     issue_a(0, 0, 0); issue_a(1, 0, 0); issue_w(2, 0, 0, n0); issue_w(3, 0, 0, n0);
     issue_a(0, 1, 1); issue_a(1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (P == 2) {                                    // (no phase 0 issue of K tile 1's weight halves in this schedule)
+        issue_w(2, 1, 1, n0); issue_w(3, 1, 1, n0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     bar();
 
     const uint32_t dk0 = DIAG ? stamp() : 0;
@@ -2195,19 +2208,22 @@ int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0, bool mx = false) {
     if (ext && best > 224) best = 224;
     if (!best) {
         long long best_cost = -1;
-        const int cand[4] = {256, 224, 192, 160};
-        for (int c = 0; c < 4; ++c) {
-            if (cand[c] <= 192 && !even_nk) continue;
+        const int cand[6] = {256, 224, 192, 160, 128, 96};
+        const bool small_ok = !mx && !ext && g_opt_p9_small;       // 128 / 96-row tiles: instances exist for the plain epilogues
+        for (int c = 0; c < (small_ok ? 6 : 4); ++c) {
+            if (cand[c] <= 192 && cand[c] >= 160 && !even_nk) continue;
             if (cand[c] > 192 && f32out && even_nk) continue;      // f32 outputs: the residual prefetch next to the accumulators spills above 192 rows
             if (cand[c] > 224 && ext) continue;                     // trainer epilogues: up to 224 rows
             if (cand[c] > 160 && mx && f32out) continue;            // MX with f32 output: 160 rows (registers)
             const long long tiles = (long long)((g.M + cand[c] - 1) / cand[c]) * (g.N / 256);
             const long long rounds = (tiles + n_cu - 1) / n_cu;
-            const long long cost = rounds * (cand[c] + 16);
+            // a K tile of a tile costs its rows + a fixed part (weight pieces, sync point); the short tiles pay the weight fetch
+            // over fewer rows and are worth it only where the taller ones leave CUs idle (tools/gemm_lab.hip, LAB_M=6304)
+            const long long cost = rounds * (cand[c] + (cand[c] < 160 ? g_opt_p9_small_fixed : 16));
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand[c]; }
         }
     }
-    if (best <= 192 && !even_nk) best = 224;
+    if (best <= 192 && best >= 160 && !even_nk) best = 224;
     if (mx) switch (best) {
         case 224: return f32out ? launch_p9_inst<7, true, 0, true>(g, st, n_cu) : launch_p9_inst<7, false, 0, true>(g, st, n_cu);
         case 192: return f32out ? launch_p9_inst<6, true, 0, true>(g, st, n_cu) : launch_p9_inst<6, false, 0, true>(g, st, n_cu);
@@ -2225,6 +2241,8 @@ int launch_p9(GemmArgs& g, hipStream_t st, int rows = 0, bool mx = false) {
         default: return launch_p9_inst<7, false, 2>(g, st, n_cu);
     }
     switch (best) {
+        case 128: return f32out ? launch_p9_inst<4, true>(g, st, n_cu) : launch_p9_inst<4, false>(g, st, n_cu);
+        case 96: return f32out ? launch_p9_inst<3, true>(g, st, n_cu) : launch_p9_inst<3, false>(g, st, n_cu);
         case 224: return f32out ? launch_p9_inst<7, true>(g, st, n_cu) : launch_p9_inst<7, false>(g, st, n_cu);
         case 192: return f32out ? launch_p9_inst<6, true>(g, st, n_cu) : launch_p9_inst<6, false>(g, st, n_cu);
         case 160: return f32out ? launch_p9_inst<5, true>(g, st, n_cu) : launch_p9_inst<5, false>(g, st, n_cu);
@@ -2555,6 +2573,9 @@ extern "C" int yv_set_option(const char* key, int value) {
     if (!key) return YV_ERR_ARG;
     if (!strcmp(key, "linear_variant")) { g_opt_variant = value; return YV_OK; }
     if (!strcmp(key, "wgrad_split_cap")) { g_opt_wgrad_cap = value; return YV_OK; }
+    if (!strcmp(key, "wgrad_split")) { g_opt_wgrad_split = value; return YV_OK; }
+    if (!strcmp(key, "linear_p9_small")) { g_opt_p9_small = value; return YV_OK; }
+    if (!strcmp(key, "linear_p9_small_fixed")) { g_opt_p9_small_fixed = value; return YV_OK; }
     if (!strcmp(key, "linear_group_m")) { g_opt_group_m = value; return YV_OK; }
     if (!strcmp(key, "staged_epilogue")) { g_opt_staged = value; return YV_OK; }
     if (!strcmp(key, "linear_p8")) { g_opt_p8 = value; return YV_OK; }
@@ -2571,6 +2592,9 @@ extern "C" int yv_get_option(const char* key, int* value) {
     if (!key || !value) return YV_ERR_ARG;
     if (!strcmp(key, "linear_variant")) { *value = g_opt_variant; return YV_OK; }
     if (!strcmp(key, "wgrad_split_cap")) { *value = g_opt_wgrad_cap; return YV_OK; }
+    if (!strcmp(key, "wgrad_split")) { *value = g_opt_wgrad_split; return YV_OK; }
+    if (!strcmp(key, "linear_p9_small")) { *value = g_opt_p9_small; return YV_OK; }
+    if (!strcmp(key, "linear_p9_small_fixed")) { *value = g_opt_p9_small_fixed; return YV_OK; }
     if (!strcmp(key, "linear_group_m")) { *value = g_opt_group_m; return YV_OK; }
     if (!strcmp(key, "staged_epilogue")) { *value = g_opt_staged; return YV_OK; }
     if (!strcmp(key, "linear_p8")) { *value = g_opt_p8; return YV_OK; }
@@ -2640,7 +2664,12 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
         // a persistent grid of 256-column tiles needs enough tiles for the chip: the trainer's 6,304 x 768 products are 120 tiles of
         // 160 rows - fewer than half the CUs - and run faster as 300 tiles of 128 x 128 at two workgroups per CU (measured: the
         // fine-tune step 9.65 -> 9.9 ms with them on the persistent kernel)
-        if (variant == 11 && g_opt_variant == 1 && (long long)((M + 159) / 160) * (N >> 8) < 192) variant = 1;
+        // (round 3, later: 96 / 128-row tiles of the free-running kernel - 198 tiles of 96 x 256 for those products - take them back
+        // where no trainer epilogue is involved)
+        if (variant == 11 && g_opt_variant == 1 && (long long)((M + 159) / 160) * (N >> 8) < 192) {
+            const bool small_ok = g_opt_p9_small && !(flags & (YV_EPI_SAVE_PRE | YV_EPI_GELU_BWD));
+            if (!small_ok || (long long)((M + 95) / 96) * (N >> 8) < 128) variant = 1;
+        }
         // free-running form (round 3): f32 outputs have the registers for 160-row tiles only, whose three-phase K tiles are walked
         // in pairs (K / 64 even); the 8-phase kernel takes the rest
         if (variant == 11 && (flags & (YV_EPI_RES_F32 | YV_EPI_OUT_F32)) && ((K / BK) & 1)) variant = 9;
@@ -2798,11 +2827,16 @@ static int wgrad_impl(const void* dY, int ldy, const void* X, int ldx, int T, in
         const long long tiles = (long long)g.tiles_m * g.tiles_n;
         // ViT weight gradients: 100+ tiles over 6k tokens -> S <= 9.  Conv weight gradients: 1-4 tiles over 10^5..10^6
         // output pixels -> up to 512 slices of >= 512 rows each (the partials stay tiny: S * Cout * 9*Cin floats)
-        int S = (int)(1024 / tiles);
+        // matrix-shaped gradients: ONE round of the 512 workgroup slots (2 per CU) - a second, partly filled round costs more than
+        // the longer slices of the first save (tools/wgrad_bench.py: dW 2304 x 768 over 6,336 tokens 43 us at S = 4 = 432
+        // workgroups, 65 us at S = 5 = 540; round 2 took 1024 / tiles = 9: 63 us)
+        int S = (int)((tiles <= 16 ? 1024 : 512) / tiles);
+        if (S < 1) S = 1;
         const int cap = tiles <= 16 ? g_opt_wgrad_cap : 16;
         const int min_rows = tiles <= 16 ? 512 : 128;
         if (S > T / min_rows) S = T / min_rows;
         if (S > cap) S = cap;
+        if (tiles > 16 && g_opt_wgrad_split > 0) S = g_opt_wgrad_split;
         const size_t fit = wsb / ((size_t)N * K * sizeof(float));
         if ((size_t)S > fit) S = (int)fit;
         if (S >= 2) { g.splitk = S; g.partial = (float*)ws; }
