@@ -43,8 +43,10 @@ def main():
     tr = VitTrainer(sd, name, 5, device="cuda:0", bucket_mb=1.0 if "tiny" in name else 32.0)
     pm = patches[lo * tok:hi * tok].to("cuda:0")
     lb = labels[lo:hi].to("cuda:0")
-    losses, grads = [], []
+    losses, grads, starts = [], [], []
     for s in range(steps):
+        if rank == 0 and s > 0:                   # parameters this step starts from (the test re-derives its gradient from them)
+            starts.append({k: v.cpu().clone() for k, v in tr.state_dict().items()})
         tr.forward(pm, hi - lo)
         loss = tr.backward(pm, lb, hi - lo)
         tr.reducer.finish()                       # all-reduced SUM of the two ranks' gradients
@@ -55,7 +57,7 @@ def main():
     torch.cuda.synchronize()
     n_buckets = len(tr.reducer.launched)
     torch.save({"state": {k: v.cpu() for k, v in tr.state_dict().items()}, "losses": losses, "buckets": n_buckets, "grads": grads,
-                "span": (lo, hi)}, out)
+                "starts": starts, "span": (lo, hi)}, out)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -77,6 +77,25 @@ def test_two_rank_step_equals_union_batch_step(tmp_path, name, R, steps):
     for s_ in range(steps):
         m = 0.5 * (ranks[0]["losses"][s_] + ranks[1]["losses"][s_])
         assert abs(m - losses[s_]) < 2e-2 * max(1.0, abs(losses[s_])), (s_, m, losses[s_])
+    # ... and the TIGHT gate for the later steps: restart a single-rank trainer from the parameters the DP run held at the start
+    # of step s and take the union batch through forward + backward - now both sides see identical parameters again, and the DP
+    # mean gradient and mean loss of step s must agree with it as tightly as at step 0 (a bucket that is launched too early in
+    # later steps, momentum or 1/world applied to the wrong buffer, a stale bf16 working copy on one rank: all O(1) here)
+    del tr
+    for s_ in range(1, steps):
+        start = {k: v.to(sd[k].dtype) for k, v in ranks[0]["starts"][s_ - 1].items()}
+        tr2 = VitTrainer(start, name, 5, device="cuda:0")
+        tr2.forward(pm, R)
+        loss2 = tr2.backward(pm, lb, R)
+        torch.cuda.synchronize()
+        g2 = {k: v.cpu() for k, v in tr2.grad_dict().items()}
+        ge = {k: rel_l2(ranks[0]["grads"][s_][k], g2[k]) for k in sd if float(g2[k].abs().max()) > 0}
+        top = sorted(ge.items(), key=lambda kv: -kv[1])[:3]
+        print(f"{name} step {s_}: DP(2) mean gradient vs union batch from the same parameters, worst: " + ", ".join(f"{k} {e:.1e}" for k, e in top))
+        assert top[0][1] < 1e-5, (s_, top)
+        m = 0.5 * (ranks[0]["losses"][s_] + ranks[1]["losses"][s_])
+        assert abs(m - float(loss2[0])) < 1e-5 * max(1.0, abs(float(loss2[0]))), (s_, m, float(loss2[0]))
+        del tr2
 
 
 def test_rccl_single_rank_step_is_bitwise_the_plain_step(tmp_path):

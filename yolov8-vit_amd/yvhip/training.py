@@ -161,7 +161,8 @@ class VitTrainer:
                  # gradients of block i run on a second stream while the main stream already writes block i-1's set
                  dy=[dict(dxb_fc2=pad(M, Mp, D), dxb_proj=pad(M, Mp, D), dwide=pad(M, Mp, 4 * D), dqkv=pad(M, Mp, 3 * D),
                           done=None) for _ in range(2)],
-                 ws=f32(max(int(lib.yv_colsum_ws_floats(M, 4 * D)), int(lib.yv_layernorm_bwd_ws_floats(M, D)), 2 * R * 128) + 64))
+                 ws=f32(max(int(lib.yv_colsum_ws_floats(M, 4 * D)), int(lib.yv_layernorm_bwd_ws_floats(M, D)), 2 * R * 128) + 64),
+                 ws_w=f32(int(lib.yv_colsum_ws_floats(M, 4 * D)) + 64))          # scratch of the column sums on the side stream
         self._bufs[R] = b
         return b
 
@@ -241,7 +242,6 @@ class VitTrainer:
             # MLP branch
             cast_colsum(dx, dxb_fc2, self.g(k + "mlp.fc2.bias"), b["ws"])
             linear_ex(dxb_fc2, self.wt(k + "mlp.fc2.weight"), None, dwide, flags=EPI_GELU_BWD, aux=b["u"][i])
-            colsum_bf16(dwide, self.g(k + "mlp.fc1.bias"), b["ws"])
             linear(dwide, self.wt(k + "mlp.fc1.weight"), None, b["dnar"])
             layernorm_bwd(xmid, D, self.p(k + "norm2.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm2.weight"), self.g(k + "norm2.bias"), b["ws"])
@@ -249,17 +249,18 @@ class VitTrainer:
             cast_colsum(dx, dxb_proj, self.g(k + "attn.proj.bias"), b["ws"])
             linear(dxb_proj, self.wt(k + "attn.proj.weight"), None, b["dnar"])
             attention_bwd(b["qkv"][i], b["o"][i], b["dnar"], b["lse"][i], R, N, H, dqkv, b["delta"])
-            colsum_bf16(dqkv, self.g(k + "attn.qkv.bias"), b["ws"])
             linear(dqkv, self.wt(k + "attn.qkv.weight"), None, b["dnar"])
             layernorm_bwd(xin, D, self.p(k + "norm1.weight"), b["dnar"], D, M, D, dx, D,
                           self.g(k + "norm1.weight"), self.g(k + "norm1.bias"), b["ws"])
-            # the block's four weight gradients: nothing on the data-gradient chain needs them, so they run on the side
-            # stream (own split-K workspace) under the next block's chain; the gradient buckets that become final with
-            # them are launched from that stream, i.e. after them
+            # the block's four weight gradients and the two bias gradients that are pure column sums (fc1, qkv): nothing on the
+            # data-gradient chain needs them, so they run on the side stream (own split-K workspace and column-sum scratch) under
+            # the next block's chain; the gradient buckets that become final with them are launched from that stream, i.e. after them
             ev = torch.cuda.Event()
             ev.record(main)
             with torch.cuda.stream(self.s_w):
                 self.s_w.wait_event(ev)
+                colsum_bf16(dwide, self.g(k + "mlp.fc1.bias"), b["ws_w"])
+                colsum_bf16(dqkv, self.g(k + "attn.qkv.bias"), b["ws_w"])
                 self._wgrad(k + "mlp.fc2.weight", S["dxb_fc2"], b["full"]["g"][i])
                 self._wgrad(k + "mlp.fc1.weight", S["dwide"], b["full"]["h2"][i])
                 self._wgrad(k + "attn.proj.weight", S["dxb_proj"], b["full"]["o"][i])
