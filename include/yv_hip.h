@@ -243,6 +243,20 @@ int yv_conv2d(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout,
               const void* weight, const float* bias, int Cout, void* out, int out_ld, const void* res, int res_ld,
               int flags, void* stream);
 
+/* One launch for a whole C2f block of the detector backbone (ultralytics C2f with shortcut, as in layers model.2 / model.4 of the
+ * YOLOv8 models the reference loads - utils/utils.py:126, test.ipynb): cv1 (1x1, 2c -> 2c), n bottlenecks of two 3x3 layers
+ * c -> c with the residual add, cv2 (1x1, (2+n)c -> 2c), SiLU after every layer (BN folded).  x (B,H,W,>=2c) bf16 with pixel
+ * stride ldx, out (B,H,W,>=2c) bf16 with pixel stride ldo; weights (Cout, k*k*Cin) bf16 with K order (ky,kx,cin) and f32
+ * biases exactly as yv_conv2d takes them; w_m / b_m: 2n entries {m0.cv1, m0.cv2, m1.cv1, m1.cv2}.  c in {16, 32}, n in {1, 2}
+ * (anything else: YV_ERR_ARG - run the block layer by layer).  Same arithmetic per output as the layer-by-layer path
+ * (K order, f32 accumulation, bias -> SiLU -> + residual -> one bf16 rounding). */
+int yv_c2f_fused(const void* x, long long ldx, int B, int H, int W, int c, int n, const void* w_cv1, const float* b_cv1,
+                 const void* const* w_m, const float* const* b_m, const void* w_cv2, const float* b_cv2, void* out,
+                 long long ldo, void* stream);
+/* Diagnostics: buf = 64 x 8 uint64 on the device receives cycle stamps (phase boundaries of wave 0 of the first 64 workgroups)
+ * of every following yv_c2f_fused launch; NULL switches them off. */
+int yv_c2f_debug(void* buf);
+
 /* Same, with a caller-owned f32 workspace: deep small-resolution layers then run split-K (K range sliced over
  * several workgroups per tile + a reduce/epilogue pass).  ws_bytes >= 8 * M * Cout * 4 enables every split. */
 int yv_conv2d_ws(const yv_view* in0, const yv_view* in1, int B, int Hout, int Wout, int ksize, int stride,

@@ -238,3 +238,63 @@ def test_vit_large_engine_shapes():
     feats = eng.backbone(pm, 2)
     torch.cuda.synchronize()
     assert feats.shape == (2, 1024) and bool(torch.isfinite(feats).all()) and float(feats[:, :1000].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("c,n,B,H,W", [(16, 1, 2, 40, 24), (32, 2, 2, 32, 32), (32, 1, 1, 17, 33), (16, 2, 1, 16, 16),
+                                       (16, 1, 2, 160, 160), (32, 2, 3, 80, 80), (32, 2, 1, 5, 70)])
+def test_c2f_fused_equals_layer_by_layer(c, n, B, H, W):
+    """yv_c2f_fused (one launch, intermediates in LDS: tile + halo, zero outside the image) against the same block run as the
+    engine runs it layer by layer (yv_conv2d x (2 + 2n): cv1, the bottlenecks' 3 x 3 pairs with the bf16 residual, cv2).  Same K
+    order, f32 accumulation and rounding chain, so the two must agree to the last bit or, where the layer kernels split K
+    differently, to one bf16 ulp of a few outputs; shapes cover ragged tiles (H, W not multiples of 16), images smaller than a
+    tile and than the halo, both channel widths and depths."""
+    import yvhip as yv
+    g = torch.Generator().manual_seed(c * 100 + n * 10 + H)
+    C1 = 2 * c
+    mk = lambda co, k: ((torch.randn(co, k, generator=g) * (2.0 / k) ** 0.5).to(torch.bfloat16).to(DEV),
+                        (torch.randn(co, generator=g) * 0.1).to(DEV))
+    w1, b1 = mk(C1, C1)
+    wm = [mk(c, 9 * c) for _ in range(2 * n)]
+    w2, b2 = mk(C1, (2 + n) * c)
+    x = torch.randn(B, H, W, C1, generator=g).to(torch.bfloat16).to(DEV)
+    # layer by layer
+    y = torch.zeros(B, H, W, (2 + n) * c, dtype=torch.bfloat16, device=DEV)
+    t = torch.zeros(B, H, W, c, dtype=torch.bfloat16, device=DEV)
+    ref = torch.zeros(B, H, W, C1, dtype=torch.bfloat16, device=DEV)
+    yv.conv2d(yv.view(x, 0, C1), None, B, H, W, 1, 1, w1, b1, y, 0, yv.EPI_SILU)
+    for j in range(n):
+        src = (1 + j) * c
+        yv.conv2d(yv.view(y, src, c), None, B, H, W, 3, 1, wm[2 * j][0], wm[2 * j][1], t, 0, yv.EPI_SILU)
+        yv.conv2d(yv.view(t, 0, c), None, B, H, W, 3, 1, wm[2 * j + 1][0], wm[2 * j + 1][1], y, src + c,
+                  yv.EPI_SILU | yv.EPI_RES_BF16, res=y, res_c_off=src)
+    yv.conv2d(yv.view(y, 0, (2 + n) * c), None, B, H, W, 1, 1, w2, b2, ref, 0, yv.EPI_SILU)
+    out = torch.full((B, H, W, C1), 7.0, dtype=torch.bfloat16, device=DEV)
+    yv.c2f_fused(x, c, n, w1, b1, [m[0] for m in wm], [m[1] for m in wm], w2, b2, out)
+    torch.cuda.synchronize()
+    a, r = out.float().cpu(), ref.float().cpu()
+    assert torch.isfinite(a).all()
+    differ = int((a != r).sum())
+    print(f"c2f c={c} n={n} {B}x{H}x{W}: {differ} of {a.numel()} outputs differ, rel-L2 {rel_l2(a, r):.2e}")
+    assert rel_l2(a, r) < 2e-3
+    assert torch.allclose(a, r, atol=2e-2, rtol=2e-2)
+    assert differ <= a.numel() // 50
+
+
+def test_yolo_engine_fused_c2f_vs_layer_by_layer():
+    """The detector with its backbone C2f blocks fused (model.2, model.4 of YOLOv8n) against the same engine running them
+    layer by layer: raw head outputs within the bf16 noise of a few re-rounded intermediates."""
+    from yvhip import engines
+    sd = oy.init_state("n", 5, seed=7)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (2, 320, 320, 3), generator=g, dtype=torch.uint8).to(DEV)
+    eng = engines.YoloEngine(sd, "n", 5, 320)
+    assert eng.fused_c2f
+    box_f, cls_f = eng.forward_raw(img)
+    f2, f4 = eng._buffers(2)["out"][2].clone(), eng._buffers(2)["out"][4].clone()
+    eng.fused_c2f = False
+    box_u, cls_u = eng.forward_raw(img)
+    u2, u4 = eng._buffers(2)["out"][2], eng._buffers(2)["out"][4]
+    torch.cuda.synchronize()
+    assert rel_l2(f2.float().cpu(), u2.float().cpu()) < 2e-3 and rel_l2(f4.float().cpu(), u4.float().cpu()) < 4e-3
+    for a, b in zip(box_f + cls_f, box_u + cls_u):
+        assert rel_l2(a.float().cpu(), b.float().cpu()) < 1e-2

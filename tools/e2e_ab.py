@@ -29,6 +29,14 @@ if spec:
     key, vals = spec.split(":")
     r_s = PipelinedRunner(pipe, split_classifier=True)          # the shipped schedule
     opts = [(f"{key}={v}", with_opt(key, int(v), r_s.submit)) for v in vals.split(",")]
+elif os.environ.get("E2E_C2F"):
+    r_s = PipelinedRunner(pipe, split_classifier=True)
+    def with_c2f(flag):
+        def run(x):
+            pipe.yolo.fused_c2f = flag
+            return r_s.submit(x)
+        return run
+    opts = [("C2f layer by layer", with_c2f(False)), ("C2f fused", with_c2f(True))]
 elif os.environ.get("E2E_SPLIT"):
     opts = [("two streams", runner.submit)] + [(f"split x{k}", PipelinedRunner(pipe, split_classifier=int(k)).submit)
                                                for k in os.environ["E2E_SPLIT"].split(",")]

@@ -78,6 +78,8 @@ _SIGS = {
     "yv_mosaic_augment": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "yv_detect_tail": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "yv_c2f_debug": (_i, [_vp]),
+    "yv_c2f_fused": (_i, [_vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp]),
     "yv_optim_step": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "yv_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
     "yv_axpby": (_i, [_vp, _vp, _sz, _f, _f, _vp]),
@@ -398,6 +400,17 @@ def detect_tail(feats, c3: int, w2, b2, w3, b3, size: int, nc: int):
     check(lib.yv_detect_tail(_p(feats[0]), _p(feats[1]), _p(feats[2]), ld, c3, arr(w2), arr(b2), arr(w3), arr(b3), B, size, nc,
                              _p(boxes), _p(scores), _st()), "yv_detect_tail")
     return boxes, scores
+
+
+def c2f_fused(x: torch.Tensor, c: int, n: int, w_cv1, b_cv1, w_m, b_m, w_cv2, b_cv2, out: torch.Tensor):
+    """One launch for a backbone C2f block (cv1, n bottlenecks with shortcut, cv2; SiLU everywhere): x (B,H,W,2c) bf16 ->
+    out (B,H,W,2c) bf16; weights (Cout, k*k*Cin) bf16 / biases f32 as conv2d takes them, w_m / b_m = [m0.cv1, m0.cv2, ...]."""
+    _chk_dev(x, out, w_cv1, b_cv1, w_cv2, b_cv2, *w_m, *b_m)
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    check(lib.yv_c2f_fused(_p(x), x.stride(2), B, H, W, c, n, _p(w_cv1), _p(b_cv1), arr(w_m), arr(b_m), _p(w_cv2), _p(b_cv2),
+                           _p(out), out.stride(2), _st()), "yv_c2f_fused")
+    return out
 
 
 # --------------------------------------------------------------- training

@@ -21,7 +21,7 @@ import torch
 from .guard import StepGuard
 from . import (set_option, EPI_GELU, EPI_OUT_F32, EPI_POSEMB, EPI_RES_BF16, EPI_RES_F32, EPI_SILU, YvError, attention, attention_mxfp8,
                cls_rows,
-               conv2d, detect_decode, detect_tail, layernorm, layernorm_mxfp8, linear, linear_mxfp8, linear_mxfp8_q, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
+               c2f_fused, conv2d, detect_decode, detect_tail, layernorm, layernorm_mxfp8, linear, linear_mxfp8, linear_mxfp8_q, quant_mxfp8, require_gpu, sppf_pool, stem_conv, view,
                wrapper_head)
 
 # --------------------------------------------------------------------------------------- YOLOv8
@@ -161,6 +161,7 @@ class YoloEngine:
             self.w[kc + ".pad16"], self.b[kc + ".pad16"] = wp16, bp16
         # fused Detect tail (yv_detect_tail: last 1 x 1 convolutions + DFL decode + sigmoid in one launch, bit-identical)
         self.fused_tail = self.c2 == 64 and nc <= 16 and self.c3 in (64, 128, 192)
+        self.fused_c2f = True                    # backbone C2f blocks with c <= 32 in one launch each (yv_c2f_fused)
         self._bufs: Dict[int, dict] = {}
         self.guard = StepGuard()                 # one replay of the launch list at a time (callers may be threads)
         self.A = sum((size // s) ** 2 for s in (8, 16, 32))
@@ -198,6 +199,12 @@ class YoloEngine:
         h = bufs["h"][idx]
         c = p["cout"] // 2
         y, t, out = bufs["y"][idx], bufs["t"][idx], bufs["out"][idx]
+        if (self.fused_c2f and in1 is None and p["add"] and p["cin"] == p["cout"] and c in (16, 32) and p["n"] in (1, 2)):
+            # the whole block in one launch, intermediates in LDS (yv_c2f_fused; YOLOv8n: model.2 and model.4)
+            keys = [pre + f"m.{j}.cv{k}.conv" for j in range(p["n"]) for k in (1, 2)]
+            c2f_fused(bufs["out"][idx - 1], c, p["n"], self.w[pre + "cv1.conv"], self.b[pre + "cv1.conv"],
+                      [self.w[k] for k in keys], [self.b[k] for k in keys], self.w[pre + "cv2.conv"], self.b[pre + "cv2.conv"], out)
+            return
         conv2d(in0, in1, B, h, h, 1, 1, self.w[pre + "cv1.conv"], self.b[pre + "cv1.conv"], y, 0, EPI_SILU)
         for j in range(p["n"]):
             src = (1 + j) * c
