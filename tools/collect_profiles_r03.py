@@ -16,6 +16,8 @@ open(P + "r03_kernel_stats_single_stream.csv", "w").write(
 for pat, name in (("gemm_p9_kernel", "r03_pmc_gemm_p9_mfma.json"), ("attention_pipe_kernel", "r03_pmc_attention_in_bench.json")):
     open(P + name, "wb").write(subprocess.check_output([sys.executable, R + "tools/pmc_kernel_summary.py", G + "mfma", pat]))
 shutil.copy(G + "attn_pmc/summary.json", P + "r03_pmc_attention_pipe.json")
+shutil.copy(G + "c2f_pmc32/summary.json", P + "r03_pmc_c2f_model4.json")
+shutil.copy(G + "c2f_pmc16/summary.json", P + "r03_pmc_c2f_model2.json")
 for b in ("32", "256"):
     f = glob.glob(G + f"pp{b}/*/*kernel_stats.csv"); assert len(f) == 1, f
     shutil.copy(f[0], P + f"r03_postproc_b{b}_kernel_stats.csv")
@@ -33,6 +35,11 @@ for src, dst, head in (("stage_split.txt", "r03_stage_split.txt", "# python3 too
                        ("attn_ablate.txt", "r03_attention_ablate.txt", "# python3 tools/attn_ablate.py (ablate 0 = shipped pipelined kernel, 5 = round-2 kernel, 11 / 12 / 13 = without fetches / compute / stores)\n"),
                        ("traffic_by_instance.txt", "r03_traffic_by_instance.txt", "# bash tools/traffic_by_instance.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py, per gemm_p9_kernel instance)\n"),
                        ("fp8_bench.txt", "r03_fp8_gemm_bench.txt", "# python3 tools/fp8_bench.py (ViT-L shapes at 50,432 rows, epilogues included)\n"),
-                       ("cus_sweep.txt", "r03_cus_sweep.txt", "# python3 tools/cus_sweep.py (pipelined step vs the CU budget of the persistent GEMMs)\n")):
+                       ("cus_sweep.txt", "r03_cus_sweep.txt", "# python3 tools/cus_sweep.py (pipelined step vs the CU budget of the persistent GEMMs)\n"),
+                       ("c2f_bench.txt", "r03_c2f_bench.txt", "# python3 tools/c2f_bench.py (backbone C2f blocks of YOLOv8n at batch 32: yv_c2f_fused vs yv_conv2d x 4 / 6)\n"),
+                       ("c2f_stamps.txt", "r03_c2f_stamps.txt", "# C2F_STAMPS=1 python3 tools/c2f_one.py (model.4: cycle stamps of wave 0 at the phase boundaries)\n"),
+                       ("wgrad_bench.txt", "r03_wgrad_bench.txt", "# python3 tools/wgrad_bench.py (weight-gradient GEMMs of the ViT-B/16 fine-tune step by number of token slices; 0 = shipped)\n"),
+                       ("gemm_lab_m6304.txt", "r03_gemm_lab_m6304.txt", "# LAB_M=6304 LAB_TRAIN=1 LAB_R1=1 tools/build/gemm_lab (the trainer's shapes: 32 images = 6,304 rows)\n"),
+                       ("e2e_c2f.txt", "r03_e2e_c2f_ab.txt", "# E2E_C2F=1 python3 tools/e2e_ab.py (whole pipelined step, backbone C2f blocks layer by layer vs fused, interleaved in one process)\n")):
     open(P + dst, "w").write(head + keep(G + src))
 print("ok")

@@ -13,3 +13,9 @@ bash $R/tools/attn_pmc.sh r03f/attn_pmc > $O/attn_pmc.log 2>&1; echo "attn pmc d
 bash $R/tools/traffic_by_instance.sh r03f/traffic > $O/traffic_by_instance.txt 2>&1; echo "traffic done"
 python3 $R/tools/fp8_bench.py > $O/fp8_bench.txt 2>&1; echo "fp8 done"
 python3 $R/tools/cus_sweep.py > $O/cus_sweep.txt 2>&1; echo "cus done"
+python3 $R/tools/c2f_bench.py > $O/c2f_bench.txt 2>&1; echo "c2f done"
+bash $R/tools/c2f_pmc.sh r03f/c2f_pmc32 > $O/c2f_pmc32.log 2>&1; C2F_C=16 C2F_N=1 C2F_H=160 bash $R/tools/c2f_pmc.sh r03f/c2f_pmc16 > $O/c2f_pmc16.log 2>&1; echo "c2f pmc done"
+C2F_STAMPS=1 python3 $R/tools/c2f_one.py > $O/c2f_stamps.txt 2>&1; echo "c2f stamps done"
+python3 $R/tools/wgrad_bench.py > $O/wgrad_bench.txt 2>&1; echo "wgrad done"
+LAB_M=6304 LAB_TRAIN=1 LAB_R1=1 timeout -k 10 300 $R/tools/build/gemm_lab > $O/gemm_lab_m6304.txt 2>&1; echo "lab 6304 done"
+E2E_C2F=1 python3 $R/tools/e2e_ab.py > $O/e2e_c2f.txt 2>&1; echo "e2e c2f done"

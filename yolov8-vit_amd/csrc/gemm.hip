@@ -1662,6 +1662,9 @@ int launch_p8(GemmArgs& g, hipStream_t st) {
 // Instances: MF (16-row fragments per wave group; tile = 32 MF rows x 256 columns) in 5..8; K / 64 >= 2, even when P is odd.
 // ---------------------------------------------------------------------------------------------
 template <int V> using ic = std::integral_constant<int, V>;
+#ifndef YV_P9_STORE_AUX
+#define YV_P9_STORE_AUX 0              // cache policy bits of the bf16 output stores (2 = nt: streaming; experiment builds only)
+#endif
 
 template <int MF, bool F32OUT, int DIAG = 0 /* tools/gemm_lab.hip only: cycle sums into g.partial */,
           int EXT = 0 /* trainer epilogues of the bf16 output: 1 = YV_EPI_SAVE_PRE (fc1 forward), 2 = YV_EPI_GELU_BWD (fc2 data gradient) */,
@@ -2098,8 +2101,8 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
                         pk[2 * i] = pack_bf16x2(v0, v1); pk[2 * i + 1] = pack_bf16x2(v2, v3);
                     }
                     const uint32_t off = m < M ? (uint32_t)((m * g.ldo + n0 + wrow_n + fq * 16) * 2) : 0x80000000u;
-                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[0], pk[1], pk[2], pk[3]}, rsO, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[4], pk[5], pk[6], pk[7]}, rsO, off, 16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[0], pk[1], pk[2], pk[3]}, rsO, off, 0, YV_P9_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk[4], pk[5], pk[6], pk[7]}, rsO, off, 16, YV_P9_STORE_AUX);
                 }
             }
         } else {
