@@ -7,10 +7,15 @@ G = R + "gpurun_out/r03f/"
 P = R + "profiles/"
 keep = lambda p: "\n".join(l for l in open(p).read().split("\n") if "amdgpu.ids" not in l)
 last = lambda p: open(p).read().strip().split("\n")[-1] + "\n"
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: a re-run leaves the older run's rocprofv3 directory beside the new one"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    assert fs, pattern
+    return [fs[-1]]
 subprocess.check_call([sys.executable, R + "tools/profile_summary.py", "r03", G + "stats", G + "fetch", G + "write"], stdout=subprocess.DEVNULL)
 open(P + "r03_bench_line.json", "w").write(last(G + "bench_line.json"))
 open(P + "r03_bench_line_under_rocprof.json", "w").write(last(G + "bench_under_rocprof.json"))
-f = glob.glob(G + "stats_single/*/*kernel_stats.csv"); assert len(f) == 1
+f = newest(G + "stats_single/*/*kernel_stats.csv")
 open(P + "r03_kernel_stats_single_stream.csv", "w").write(
     "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-traffic --no-overlap\n" + open(f[0]).read())
 for pat, name in (("gemm_p9_kernel", "r03_pmc_gemm_p9_mfma.json"), ("attention_pipe_kernel", "r03_pmc_attention_in_bench.json")):
@@ -19,7 +24,7 @@ shutil.copy(G + "attn_pmc/summary.json", P + "r03_pmc_attention_pipe.json")
 shutil.copy(G + "c2f_pmc32/summary.json", P + "r03_pmc_c2f_model4.json")
 shutil.copy(G + "c2f_pmc16/summary.json", P + "r03_pmc_c2f_model2.json")
 for b in ("32", "256"):
-    f = glob.glob(G + f"pp{b}/*/*kernel_stats.csv"); assert len(f) == 1, f
+    f = newest(G + f"pp{b}/*/*kernel_stats.csv")
     shutil.copy(f[0], P + f"r03_postproc_b{b}_kernel_stats.csv")
 json.dump([json.loads(open(G + f"pp{b}_line.json").read()) for b in ("32", "256")], open(P + "r03_postproc_bench_lines.json", "w"), indent=1)
 json.dump([json.loads(l) for l in open(G + "other_modes.jsonl")], open(P + "r03_bench_lines_other_modes.json", "w"), indent=1)
@@ -28,7 +33,7 @@ for n in ("train_vit", "train_yolo"):
         f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --mode {'train' if n == 'train_vit' else 'train-yolo'} --steps 10 --warmup 3 --no-cpu-baseline\n"
         + open(G + f"train/{n}_kernel_stats.csv").read())
 json.dump({n: json.loads(last(G + f"train/{n}_line.json")) for n in ("train_vit", "train_yolo")}, open(P + "r03_train_bench_lines.json", "w"), indent=1)
-f = glob.glob(G + "det/*/*kernel_stats.csv"); assert len(f) == 1, f
+f = newest(G + "det/*/*kernel_stats.csv")
 shutil.copy(f[0], P + "r03_detect_stage_kernel_stats.csv")
 for src, dst, head in (("stage_split.txt", "r03_stage_split.txt", "# python3 tools/stage_split.py (one process, interleaved; ms per batch of 32 images / 128 crops)\n"),
                        ("conv_layers.txt", "r03_conv_layers.txt", ""), ("gemm_lab.txt", "r03_gemm_lab.txt", "# tools/build/gemm_lab (stand-alone, interleaved in one process; p8 = round-2 kernel, p9 = shipped)\n"),

@@ -2637,7 +2637,11 @@ static int linear_impl(const void* A, int lda, const void* W, const float* bias,
         // over 6336 tokens is 108 tiles for 256 CUs; slicing K fills the chip.  Deterministic: partial sums go to
         // the stream's workspace and are added in slice order by splitk_reduce_kernel.
         void* ws = nullptr; size_t wsb = 0;
-        if (g_opt_linear_splitk && !(flags & ~(YV_EPI_BIAS | YV_EPI_OUT_F32)) && !m_dev && ws_lookup((void*)stream, &ws, &wsb)) {
+        // (not where the free-running kernel's 96-row tiles fill the chip in one round: the trainer's 6,304 x 768 data gradients were
+        // two K slices of 300 tiles + a reduce pass; as 198 tiles of 96 x 256 the fine-tune step is 9.20 -> 9.00 ms)
+        const bool p9_small_route = g_opt_variant == 1 && g_opt_p8 >= 3 && g_opt_p9_small && !(N & 255) && N <= 4096 && M >= 2048 &&
+                                    K >= 128 && (long long)((M + 95) / 96) * (N >> 8) >= 128 && !(ldo & 7);
+        if (g_opt_linear_splitk && !p9_small_route && !(flags & ~(YV_EPI_BIAS | YV_EPI_OUT_F32)) && !m_dev && ws_lookup((void*)stream, &ws, &wsb)) {
             const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
             const int nk = K / BK;
             int S = (int)(768 / tiles);

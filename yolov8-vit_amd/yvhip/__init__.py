@@ -889,3 +889,10 @@ def attention_mxfp8(qkv: torch.Tensor, R: int, N: int, H: int, out_q: torch.Tens
     _chk_dev(qkv, out_q, out_scale, r_dev)
     check(lib.yv_attention_mxfp8(_p(qkv), R, N, H, float(64 ** -0.5 if scale is None else scale), _p(out_q), out_q.stride(0),
                                  _p(out_scale), out_scale.shape[1], _p(r_dev), _st()), "yv_attention_mxfp8")
+
+
+# development knob: YV_OPTIONS="key=value,key=value" applies yv_set_option pairs at import (A/B runs of bench.py / tools without
+# editing them); unknown keys fail loudly
+for _kv in filter(None, os.environ.get("YV_OPTIONS", "").split(",")):
+    _k, _v = _kv.split("=")
+    set_option(_k.strip(), int(_v))
