@@ -159,6 +159,8 @@ int yv_compact_crops_split(const int32_t* det_count, const int32_t* crop_rect, c
 int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, size_t img_stride, const int32_t* crop_list,
                         const int32_t* crop_total, int cap, int out_size, int patch, int layout, void* out,
                         void* stream);
+/* Diagnostics: forced number of 16-row groups a block of the crop kernel walks (0 = chosen from the crop count). */
+int yv_crop_debug(int groups_per_block);
 
 /* letterbox (YOLOTensorRT_yolodet_py_解读.md:67-69): src (B,Hc,Wc,3) u8 canvas holding image b in its top-left
  * w x h corner; geom (B,6) i32 rows {w, h, nw, nh, left, top} (host-computed);

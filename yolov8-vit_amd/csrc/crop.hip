@@ -19,7 +19,7 @@ namespace {
 constexpr int CR_THREADS = 256;
 constexpr int CR_MAX_S = 512;
 constexpr int CR_ROWS = 16;                  // source rows staged per block (= output rows per block)
-constexpr int CR_ROWB = 2048;                // bytes per staged row segment: crops up to 677 pixels wide, wider ones gather from global
+constexpr int CR_BUF = 16 * 1032;             // bytes of the staging buffer (see the kernel)
 
 __device__ __forceinline__ int nearest_src(int d, int dst, int src) {
     double fx = __ddiv_rn((double)dst, (double)src);
@@ -36,80 +36,117 @@ template <int LAYOUT>
 __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restrict__ images, int H, int W,
                                                           size_t img_stride, const int32_t* __restrict__ crop_list,
                                                           const int32_t* __restrict__ crop_total, int S, int P,
-                                                          int rows_per_block, float rcp, void* __restrict__ out, int n_images) {
+                                                          int rows_per_block, float rcp, void* __restrict__ out, int n_images,
+                                                          int groups_per_block) {
     __shared__ int tx[CR_MAX_S];
     __shared__ int ty_sh[64];
     __shared__ int rshift[CR_ROWS];
-    __shared__ __attribute__((aligned(16))) unsigned char rowbuf[CR_ROWS][CR_ROWB + 8];   // (+8: the rows of a column sit in different banks)
+    __shared__ __attribute__((aligned(16))) unsigned char rowbuf[LAYOUT == 2 ? CR_BUF : 16];
     const int r = blockIdx.y;
     if (crop_total && r >= crop_total[0]) return;
     const int32_t* rec = crop_list + (size_t)r * 6;
     const int img = rec[0], x0 = rec[1], y0 = rec[2], x1 = rec[3], y1 = rec[4];
     const int cw = x1 - x0, ch = y1 - y0;
-    const int row0 = blockIdx.x * rows_per_block;
     if (cw <= 0 || ch <= 0) return;      // degenerate rect: compaction never emits one; guard anyway
     // a record that does not lie inside an image of the batch is never read from (defence against a corrupted list:
     // an out-of-range gather would be a GPU memory fault)
     if (img < 0 || img >= n_images || x0 < 0 || y0 < 0 || x1 > W || y1 > H) return;
     for (int d = threadIdx.x; d < S; d += CR_THREADS) tx[d] = (x0 + nearest_src(d, S, cw)) * 3;
+    const uint8_t* src = images + (size_t)img * img_stride;
+    // A block walks groups_per_block consecutive row groups of its crop: the chain in front of the first useful byte - crop count,
+    // crop record, the f64 column table, a barrier - is ~3 us of dependent latency, and at 1,024 crops x 14 groups the kernel was
+    // 14,336 blocks of 21 KB each, waves parked 75 % of their cycles (profiles/r03_pmc_crop.json).  Few crops: one group per block
+    // (the grid must still fill the chip).
+    for (int gi = 0; gi < groups_per_block; ++gi) {
+    const int row0 = (blockIdx.x * groups_per_block + gi) * rows_per_block;
+    if (row0 >= S) break;
+    if (gi) __syncthreads();             // the previous group's gathers are done with ty_sh / the staging buffer
     for (int d = threadIdx.x; d < rows_per_block; d += CR_THREADS) ty_sh[d] = y0 + nearest_src(row0 + d, S, ch);
     __syncthreads();
-    const uint8_t* src = images + (size_t)img * img_stride;
-    // Source rows through LDS.  A per-lane BYTE gather from global memory costs the texture path about a lane per clock whatever
-    // the cache does (measured on the detector's stem: 32 such loads per 64 pixels = 80-100 us per 32 images, 44 us once
-    // staged), and this kernel did 24 of them per 8 output pixels.  The block's rows_per_block source-row segments
-    // [3 x0, 3 x1) are copied with 8-byte loads of ALIGNED words (the word holding a valid byte lies in that byte's page,
-    // so the up to 7 bytes read around a segment can never fault), then gathered byte by byte from LDS.
-    const bool staged = rows_per_block <= CR_ROWS && cw * 3 + 16 <= CR_ROWB;
-    if (staged) {
-        const int words = (cw * 3 + 7 + 7) >> 3;                 // 8-byte words that cover a segment at any alignment
-        for (int it = threadIdx.x; it < rows_per_block * words; it += CR_THREADS) {
-            const int yl = it / words, u = it - yl * words;
-            const uintptr_t first = (uintptr_t)(src + (size_t)ty_sh[yl] * (size_t)W * 3 + (size_t)x0 * 3);
-            const int lead = (int)(first & 7);
-            if (u == 0) rshift[yl] = lead - x0 * 3;              // LDS byte of source byte b of the row = rshift + b
-            if (u * 8 < lead + cw * 3)                           // only words that hold a byte of the segment
-                *(uint2*)(rowbuf[yl] + u * 8) = *(const uint2*)((first & ~(uintptr_t)7) + (size_t)u * 8);
-        }
-        __syncthreads();
-    }
     const int groups = S >> 3;                       // 8 output pixels per item
     if (LAYOUT == 2) {
+        // Source rows through LDS.  A per-lane BYTE gather from global memory costs the texture path about a lane per clock whatever
+        // the cache does (measured on the detector's stem: 32 such loads per 64 pixels = 80-100 us per 32 images, 44 us once
+        // staged), and this kernel did 24 of them per 8 output pixels.  The source-row segments [3 x0, 3 x1) of a PASS of rows are
+        // copied with 8-byte loads of ALIGNED words (the word holding a valid byte lies in that byte's page, so the up to 7 bytes
+        // read around a segment can never fault), then gathered byte by byte from LDS.  The buffer is 16.5 KB - eight blocks per
+        // CU; at 33 KB / four blocks the kernel moved 3.8 TB/s, waves parked 75 % of their cycles, now 4.9 - and holds as many
+        // rows per pass as fit: 16 for crops up to 336 pixels wide, 8 up to 680, ... 1 up to 5,496.
+        const int words = (cw * 3 + 7 + 7) >> 3;             // 8-byte words that cover a segment at any alignment
+        const int pitch = (words + 1 + (words & 1)) * 8;     // an ODD number of 8-byte words: the 16 rows of a column sit in 16 different banks
+        int rpp = CR_BUF / pitch;
+        rpp = rpp >= 16 ? 16 : rpp >= 8 ? 8 : rpp >= 4 ? 4 : rpp >= 2 ? 2 : rpp;
+        if (rpp > rows_per_block) rpp = rows_per_block;
+        const bool staged = rpp >= 1 && rows_per_block <= CR_ROWS;
+        const int nrows = staged ? rpp : rows_per_block;
+        const int lg_rows = 31 - __builtin_clz(nrows);      // (a power of two on the by-patch path)
         // patch-major bf16 (the classifier's operand): one item = 8 consecutive output pixels of a row, ALL THREE channels - the
         // 8 column-table reads and the row / patch arithmetic are shared by the channels, and the 24 source bytes are 8 runs
         // of 3 adjacent bytes (the first version gave each channel its own item: three times the LDS reads and index math for
         // the same bytes)
-        const int items = rows_per_block * groups;
+        const int items = nrows * groups;
         const int gp = S / P;                        // patches per side
-        auto run = [&](auto line_of) __attribute__((always_inline)) {
-            for (int it = threadIdx.x; it < items; it += CR_THREADS) {
-                // one patch row per block (P = 16 = rows_per_block): consecutive lanes take the two 8-pixel halves of consecutive
-                // rows of ONE patch, whose (channel, 16 x 16) block is 512 contiguous bytes of the operand - a wave's store is
-                // two full blocks instead of 32-byte pieces of 28 of them
-                const bool by_patch = P == 16 && rows_per_block == 16;
-                const int g = by_patch ? ((it >> 5) << 1) | (it & 1) : it % groups;
-                const int yl = by_patch ? (it >> 1) & 15 : it / groups;
-                const int y = row0 + yl, x = g * 8;
-                const auto line = line_of(yl);
-                float v[3][8];
+        for (int r_begin = 0; r_begin < rows_per_block; r_begin += nrows) {
+            if (staged) {
+                if (r_begin) __syncthreads();                    // the previous pass's gathers are done with the buffer
+                const int nst = nrows * words;
+                // four words per thread and trip, ALL loaded before the first is stored: one memory round trip per trip (a loop of
+                // load -> LDS store pairs paid the full HBM latency per iteration, 3-4 of them for a 150-pixel crop)
+                for (int base = threadIdx.x; base < nst; base += 4 * CR_THREADS) {
+                    uint2 wv[4];
+                    unsigned char* dst[4];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const auto px = line + tx[x + q];
+                    for (int k = 0; k < 4; ++k) {
+                        const int it = base + k * CR_THREADS;
+                        dst[k] = nullptr;
+                        if (it < nst) {
+                            const int yp = it / words, u = it - yp * words;
+                            const int yl = r_begin + yp;
+                            const uintptr_t first = (uintptr_t)(src + (size_t)ty_sh[yl] * (size_t)W * 3 + (size_t)x0 * 3);
+                            const int lead = (int)(first & 7);
+                            if (u == 0) rshift[yl] = yp * pitch + lead - x0 * 3;   // LDS byte of source byte b of the row = rshift + b
+                            if (u * 8 < lead + cw * 3) {         // only words that hold a byte of the segment
+                                wv[k] = *(const uint2*)((first & ~(uintptr_t)7) + (size_t)u * 8);
+                                dst[k] = rowbuf + yp * pitch + u * 8;
+                            }
+                        }
+                    }
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c][q] = norm_u8(px[c], rcp);
+                    for (int k = 0; k < 4; ++k)
+                        if (dst[k]) *(uint2*)dst[k] = wv[k];
                 }
-                const size_t row = (size_t)r * gp * gp + (size_t)(y / P) * gp + (x / P);
-                uint16_t* o = (uint16_t*)out + row * (size_t)(3 * P * P) + (y % P) * P + (x % P);
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    *(uint4*)(o + (size_t)c * P * P) = make_uint4(pack_bf16x2(v[c][0], v[c][1]), pack_bf16x2(v[c][2], v[c][3]),
-                                                                  pack_bf16x2(v[c][4], v[c][5]), pack_bf16x2(v[c][6], v[c][7]));
+                __syncthreads();
             }
-        };
-        // (two instantiations so that the staged one reads LDS with ds_read_u8 rather than through a generic pointer)
-        if (staged) run([&](int yl) __attribute__((always_inline)) { return (const uint8_t*)rowbuf[yl] + rshift[yl]; });
-        else run([&](int yl) __attribute__((always_inline)) { return src + (size_t)ty_sh[yl] * (size_t)W * 3; });
-        return;
+            auto run = [&](auto line_of) __attribute__((always_inline)) {
+                for (int it = threadIdx.x; it < items; it += CR_THREADS) {
+                    // one patch row per block (P = 16 = rows_per_block): consecutive lanes take the two 8-pixel halves of consecutive
+                    // rows of ONE patch, whose (channel, 16 x 16) block is 512 contiguous bytes of the operand - a wave's store is
+                    // two full blocks (16-row passes) instead of 32-byte pieces of 28 of them
+                    const bool by_patch = P == 16 && rows_per_block == 16;
+                    const int g = by_patch ? ((it >> (1 + lg_rows)) << 1) | (it & 1) : it % groups;
+                    const int yl = r_begin + (by_patch ? (it >> 1) & (nrows - 1) : it / groups);
+                    const int y = row0 + yl, x = g * 8;
+                    const auto line = line_of(yl);
+                    float v[3][8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const auto px = line + tx[x + q];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) v[c][q] = norm_u8(px[c], rcp);
+                    }
+                    const size_t row = (size_t)r * gp * gp + (size_t)(y / P) * gp + (x / P);
+                    uint16_t* o = (uint16_t*)out + row * (size_t)(3 * P * P) + (y % P) * P + (x % P);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        *(uint4*)(o + (size_t)c * P * P) = make_uint4(pack_bf16x2(v[c][0], v[c][1]), pack_bf16x2(v[c][2], v[c][3]),
+                                                                      pack_bf16x2(v[c][4], v[c][5]), pack_bf16x2(v[c][6], v[c][7]));
+                }
+            };
+            // (two instantiations so that the staged one reads LDS with ds_read_u8 rather than through a generic pointer)
+            if (staged) run([&](int yl) __attribute__((always_inline)) { return (const uint8_t*)rowbuf + rshift[yl]; });
+            else run([&](int yl) __attribute__((always_inline)) { return src + (size_t)ty_sh[yl] * (size_t)W * 3; });
+        }
+        continue;
     }
     const int items = rows_per_block * 3 * groups;
     for (int it = threadIdx.x; it < items; it += CR_THREADS) {
@@ -132,6 +169,7 @@ __global__ __launch_bounds__(CR_THREADS) void crop_kernel(const uint8_t* __restr
                                     pack_bf16x2(v[6], v[7]));
         }
     }
+    }   // row groups of this block
 }
 
 
@@ -173,7 +211,11 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
     }
 }
 
+int g_crop_gpb = 0;                 // > 0: forced row groups per block (yv_crop_debug)
+
 }  // namespace
+
+extern "C" int yv_crop_debug(int groups_per_block) { g_crop_gpb = groups_per_block; return YV_OK; }
 
 extern "C" int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, size_t img_stride,
                                    const int32_t* crop_list, const int32_t* crop_total, int cap, int out_size,
@@ -187,17 +229,22 @@ extern "C" int yv_crop_resize_norm(const uint8_t* images, int B, int H, int W, s
     int rows = 16;
     if (out_size % rows) rows = 8;
     const float rcp = 1.0f / 127.5f;                 // fl32(1/127.5), computed once on the host
-    dim3 grid(out_size / rows, cap), block(CR_THREADS);
+    // row groups per block: two where the list is long enough to keep every CU's eight block slots busy regardless
+    const int ngroups = out_size / rows;
+    // (measured at 1,024 crops x 14 groups: 1 -> 96 us, 2 -> 94, 4 -> 108, 14 -> 131; at 128 crops 1 -> 14.1, 2 -> 16.0)
+    int gpb = g_crop_gpb > 0 ? g_crop_gpb : ((long long)cap * ngroups >= 8192 ? 2 : 1);
+    gpb = gpb < 1 ? 1 : (gpb > ngroups ? ngroups : gpb);
+    dim3 grid((ngroups + gpb - 1) / gpb, cap), block(CR_THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (layout == 0)
         hipLaunchKernelGGL(crop_kernel<0>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
-                           out_size, patch, rows, rcp, out, B);
+                           out_size, patch, rows, rcp, out, B, gpb);
     else if (layout == 1)
         hipLaunchKernelGGL(crop_kernel<1>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
-                           out_size, patch, rows, rcp, out, B);
+                           out_size, patch, rows, rcp, out, B, gpb);
     else
         hipLaunchKernelGGL(crop_kernel<2>, grid, block, 0, st, images, H, W, img_stride, crop_list, crop_total,
-                           out_size, patch, rows, rcp, out, B);
+                           out_size, patch, rows, rcp, out, B, gpb);
     return yv_launch_status();
 }
 

@@ -79,6 +79,7 @@ _SIGS = {
     "yv_detect_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "yv_detect_tail": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "yv_c2f_debug": (_i, [_vp]),
+    "yv_crop_debug": (_i, [_i]),
     "yv_c2f_fused": (_i, [_vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp]),
     "yv_optim_step": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "yv_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
