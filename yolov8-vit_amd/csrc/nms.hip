@@ -386,16 +386,29 @@ __global__ __launch_bounds__(EN2_FT) void en2_filter_kernel(const float* __restr
     const int i0 = blockIdx.x * (EN2_FT * EN2_FPT);
     const bool cc_lds = nc <= EN2_CC_LDS;
     if (cc_lds) for (int c = tid; c < nc; c += EN2_FT) cc[c] = 0;
+    // element j of this thread is score number idx(j): 16-byte loads (a wave reads 1 KB per instruction) where the image's score
+    // block allows them (16-byte aligned, the chunk inside `total`), 4-byte loads otherwise; the list is a SET (every consumer
+    // orders it by key), so the order in which a chunk's candidates are written does not matter
+    const bool vec = (((uintptr_t)S & 15) == 0) && i0 + EN2_FT * EN2_FPT <= total;
+    auto idx = [&](int j) __attribute__((always_inline)) { return vec ? i0 + ((j >> 2) * EN2_FT + tid) * 4 + (j & 3) : i0 + j * EN2_FT + tid; };
     float v[EN2_FPT];
+    if (vec) {
 #pragma unroll
-    for (int j = 0; j < EN2_FPT; ++j) {                  // all loads in flight; lane-contiguous 256-byte wave accesses
-        const int i = i0 + j * EN2_FT + tid;
-        v[j] = i < total ? S[i] : 0.0f;
+        for (int j4 = 0; j4 < EN2_FPT / 4; ++j4) {           // all loads in flight
+            const float4 q4 = *(const float4*)(S + i0 + (j4 * EN2_FT + tid) * 4);
+            v[4 * j4] = q4.x; v[4 * j4 + 1] = q4.y; v[4 * j4 + 2] = q4.z; v[4 * j4 + 3] = q4.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < EN2_FPT; ++j) {                  // all loads in flight; lane-contiguous 256-byte wave accesses
+            const int i = i0 + j * EN2_FT + tid;
+            v[j] = i < total ? S[i] : 0.0f;
+        }
     }
     uint32_t mine = 0;
 #pragma unroll
     for (int j = 0; j < EN2_FPT; ++j) {
-        const int i = i0 + j * EN2_FT + tid;
+        const int i = idx(j);
         mine += (i < total && v[j] > thr) ? 1u : 0u;
     }
     // exclusive rank of this thread's candidates inside the workgroup
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(EN2_FT) void en2_filter_kernel(const float* __restr
     uint64_t* list = ws.cand + (size_t)b * ws.lcap;
 #pragma unroll
     for (int j = 0; j < EN2_FPT; ++j) {
-        const int i = i0 + j * EN2_FT + tid;
+        const int i = idx(j);
         if (i < total && v[j] > thr) {
             if (pos < (uint32_t)ws.lcap) list[pos] = ((uint64_t)desc_key(v[j]) << 32) | (uint32_t)i;
             ++pos;
