@@ -22,6 +22,13 @@ for pat, name in (("gemm_p9_kernel", "r03_pmc_gemm_p9_mfma.json"), ("attention_p
     open(P + name, "wb").write(subprocess.check_output([sys.executable, R + "tools/pmc_kernel_summary.py", G + "mfma", pat]))
 shutil.copy(G + "attn_pmc/summary.json", P + "r03_pmc_attention_pipe.json")
 shutil.copy(G + "c2f_pmc32/summary.json", P + "r03_pmc_c2f_model4.json")
+shutil.copy(G + "crop_pmc/summary.json", P + "r03_pmc_crop.json")
+shutil.copy(G + "nms_pmc/summary.json", P + "r03_pmc_nms_front.json")
+with open(P + "r03_postproc_batch_sweep.txt", "w") as f_:
+    f_.write("# for b in 8 32 128 256 512 1024: python3 bench.py --mode postproc --batch b  (EfficientNMS call = en2_filter + en2_front + en2_tail; crop_kernel<2> at 4 crops per image)\n")
+    for l_ in open(G + "pp_sweep.jsonl"):
+        d_ = json.loads(l_)
+        f_.write("%5d images: NMS %6.1f us %5.1f %% of 8 TB/s | crop (4 per image) %6.1f us %5.1f %%\n" % (d_["config"]["batch"], d_["roofline"]["us_per_call"], d_["roofline"]["frac"] * 100, d_["crop_roofline"]["us_per_call"], d_["crop_roofline"]["frac"] * 100))
 shutil.copy(G + "c2f_pmc16/summary.json", P + "r03_pmc_c2f_model2.json")
 for b in ("32", "256"):
     f = newest(G + f"pp{b}/*/*kernel_stats.csv")
@@ -45,6 +52,8 @@ for src, dst, head in (("stage_split.txt", "r03_stage_split.txt", "# python3 too
                        ("c2f_stamps.txt", "r03_c2f_stamps.txt", "# C2F_STAMPS=1 python3 tools/c2f_one.py (model.4: cycle stamps of wave 0 at the phase boundaries)\n"),
                        ("wgrad_bench.txt", "r03_wgrad_bench.txt", "# python3 tools/wgrad_bench.py (weight-gradient GEMMs of the ViT-B/16 fine-tune step by number of token slices; 0 = shipped)\n"),
                        ("gemm_lab_m6304.txt", "r03_gemm_lab_m6304.txt", "# LAB_M=6304 LAB_TRAIN=1 LAB_R1=1 tools/build/gemm_lab (the trainer's shapes: 32 images = 6,304 rows)\n"),
+                       ("crop_bench.txt", "r03_crop_bench.txt", "# python3 tools/crop_bench.py (crop_kernel<2> by row groups per block; 0 = the launcher's choice; 'wide' = 340-640 pixel boxes)\n"),
+                       ("write_ceiling.txt", "r03_write_ceiling.txt", "# python3 tools/write_ceiling.py (plain torch fill / copy of the crop kernel's 308 MB output: what a streaming kernel reaches on this box)\n"),
                        ("e2e_c2f.txt", "r03_e2e_c2f_ab.txt", "# E2E_C2F=1 python3 tools/e2e_ab.py (whole pipelined step, backbone C2f blocks layer by layer vs fused, interleaved in one process)\n")):
     open(P + dst, "w").write(head + keep(G + src))
 print("ok")

@@ -19,3 +19,7 @@ C2F_STAMPS=1 python3 $R/tools/c2f_one.py > $O/c2f_stamps.txt 2>&1; echo "c2f sta
 python3 $R/tools/wgrad_bench.py > $O/wgrad_bench.txt 2>&1; echo "wgrad done"
 LAB_M=6304 LAB_TRAIN=1 LAB_R1=1 timeout -k 10 300 $R/tools/build/gemm_lab > $O/gemm_lab_m6304.txt 2>&1; echo "lab 6304 done"
 E2E_C2F=1 python3 $R/tools/e2e_ab.py > $O/e2e_c2f.txt 2>&1; echo "e2e c2f done"
+python3 $R/tools/crop_bench.py > $O/crop_bench.txt 2>&1; echo "crop done"
+bash $R/tools/crop_pmc.sh r03f/crop_pmc > $O/crop_pmc.log 2>&1; bash $R/tools/nms_pmc.sh r03f/nms_pmc > $O/nms_pmc.log 2>&1; echo "crop / nms pmc done"
+python3 $R/tools/write_ceiling.py > $O/write_ceiling.txt 2>&1
+for b in 8 32 128 256 512 1024; do python3 $R/bench.py --mode postproc --batch $b 2>/dev/null | tail -1; done > $O/pp_sweep.jsonl; echo "sweep done"
