@@ -179,6 +179,13 @@ int main(int argc, char** argv) {
     printf("device %s, %d CUs, M = %d\n", prop.name, n_cu, M);
     std::vector<Problem> ps = {make_problem("qkv", M, 2304, 768, 0), make_problem("proj", M, 768, 768, YV_EPI_RES_F32),
                                make_problem("fc1", M, 3072, 768, YV_EPI_GELU), make_problem("fc2", M, 768, 3072, YV_EPI_RES_F32)};
+    if (getenv("LAB_CAL")) {
+        // calibration of the FETCH_SIZE counter on THIS kernel's access pattern (run under rocprofv3 --pmc FETCH_SIZE): one column
+        // tile, so no activation row has a second reader - the kernel must fetch A exactly once (+ 0.4 MB of W per XCD)
+        ps.clear();
+        ps.push_back(make_problem("cal256", M, 256, 768, 0));
+        ps.push_back(make_problem("cal512", M, 512, 768, 0));
+    }
     if (getenv("LAB_TRAIN")) {                                  // the trainer's data-gradient products with 768 outputs (bf16)
         ps.push_back(make_problem("dqkv", M, 768, 2304, 0));
         ps.push_back(make_problem("dfc1", M, 768, 3072, 0));
@@ -223,7 +230,7 @@ int main(int argc, char** argv) {
     }
     for (size_t v = 0; v < vs.size(); ++v)
         printf("LAYER %-24s %7.1f us  flop-weighted frac %.3f\n", vs[v].name.c_str(), tot_us[v], tot_fl / tot_us[v] / 1e6 / 2500.0);
-    if (!getenv("LAB_NO_DIAG") && !getenv("LAB_TRAIN")) {
+    if (!getenv("LAB_NO_DIAG") && !getenv("LAB_TRAIN") && !getenv("LAB_CAL")) {
         run_diag9<7, false>(ps[0], n_cu);
         run_diag9<5, true>(ps[1], n_cu);
         run_diag9<8, false>(ps[2], n_cu);

@@ -2452,6 +2452,13 @@ int dispatch(GemmArgs& g, hipStream_t st) {
             if (g_opt_conv_dma == 2) return launch_cdma<64, 4, 1, 3>(g, st);
             if (g_opt_conv_dma == 3) return g.N > 64 ? launch_cdma<128, 2, 2, 3>(g, st) : launch_cdma<64, 4, 1, 3>(g, st);
             if (g_opt_conv_dma == 4) return launch_cdma<64, 4, 1, 4>(g, st);
+            if (g_opt_conv_dma == 5) {      // by reduction depth: deep K (>= 1024) three stages / 64-wide, shallow K two stages
+                if (g.K >= 1024) return launch_cdma<64, 4, 1, 3>(g, st);
+                return g.N > 64 ? launch_cdma<128, 2, 2, 2>(g, st) : launch_cdma<64, 4, 1, 2>(g, st);
+            }
+            if (g_opt_conv_dma == 6) {      // as 5, but 64-wide tiles everywhere
+                return g.K >= 1024 ? launch_cdma<64, 4, 1, 3>(g, st) : launch_cdma<64, 4, 1, 2>(g, st);
+            }
             return g.N > 64 ? launch_cdma<128, 2, 2, 2>(g, st) : launch_cdma<64, 4, 1, 2>(g, st);
         }
     }
