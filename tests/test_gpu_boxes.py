@@ -346,15 +346,19 @@ def test_crop_resize_norm_bit_exact(yv):
 
 
 def test_crop_wide_sources_both_gather_paths(yv):
-    """Camera-sized sources (1080 x 1920, a row is not a multiple of 8 bytes): crops narrower than 677 pixels go through the
-    LDS-staged gather (aligned 8-byte loads around arbitrary byte offsets, first / last pixel of the buffer included), wider
-    ones through the direct global gather; both bit for bit against the oracle, all three layouts."""
+    """Camera-sized sources (1080 x 1920, a row is not a multiple of 8 bytes).  The patch-major layout stages its source rows
+    through a 16.5 KB LDS buffer in passes of as many rows as fit: 16 rows for crops up to 336 pixels wide, 8 up to 680, 4 up to
+    1,370, 2 beyond (aligned 8-byte loads around arbitrary byte offsets, first / last pixel of the buffer included) - the widths
+    below sit on both sides of every pass boundary; the planar layouts gather from global memory.  Bit for bit against the
+    oracle, and the same bits whatever number of row groups a block walks (yv_crop_debug)."""
     H, W = 1080, 1921
     g = torch.Generator().manual_seed(5)
     imgs = torch.randint(0, 256, (2, H, W, 3), generator=g, dtype=torch.uint8)
     rects = [(0, 0, 0, 1921, 1080, 0), (1, 1200, 1000, 1921, 1080, 0), (0, 0, 0, 677, 5, 0), (1, 1, 1, 679, 400, 0),
              (1, 1244, 3, 1921, 1080, 0), (0, 1920, 1079, 1921, 1080, 0), (1, 1913, 1070, 1921, 1080, 0), (0, 0, 0, 1, 1, 0),
-             (1, 333, 777, 1009, 1011, 0), (0, 5, 5, 683, 300, 0)]
+             (1, 333, 777, 1009, 1011, 0), (0, 5, 5, 683, 300, 0),
+             (0, 3, 10, 339, 200, 0), (0, 3, 10, 340, 200, 0), (1, 7, 20, 687, 300, 0), (1, 7, 20, 688, 333, 0),
+             (0, 1, 0, 1371, 500, 0), (0, 1, 0, 1372, 500, 0), (1, 0, 100, 1500, 1080, 0)]
     cl = torch.tensor(rects, dtype=torch.int32, device=DEV)
     tot = torch.tensor([len(rects)], dtype=torch.int32, device=DEV)
     dimg = imgs.to(DEV)
@@ -364,6 +368,12 @@ def test_crop_wide_sources_both_gather_paths(yv):
         exp = ob.crop_resize_normalize(imgs[rc[0]].numpy(), rc[1:5])
         assert np.array_equal(f32[r].numpy(), exp), r
         assert torch.equal(pm[r * 196:(r + 1) * 196], torch.from_numpy(ob.patchify(exp, 16)).to(torch.bfloat16)), r
+    try:
+        for gpb in (1, 2, 5, 14):
+            yv.lib.yv_crop_debug(gpb)
+            assert torch.equal(yv.crop_resize_norm(dimg, cl, tot, len(rects), 224, 16, layout=2).cpu(), pm), gpb
+    finally:
+        yv.lib.yv_crop_debug(0)
 
 
 def test_crop_gather_at_bench_batch(yv):
