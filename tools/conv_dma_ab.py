@@ -14,7 +14,7 @@ pipe = DetectClassifyPipeline(engines.YoloEngine(engines.init_yolo_state("n", 5,
 g = torch.Generator().manual_seed(1234)
 images = torch.randint(0, 256, (32, 640, 640, 3), generator=g, dtype=torch.uint8).to(dev)
 runner = PipelinedRunner(pipe, split_classifier=True)
-vals = [int(v) for v in os.environ.get("CONV_DMA", "2,1,5,6").split(",")]
+vals = [int(v) for v in os.environ.get("CONV_DMA", "8,2,1,7").split(",")]
 res = {(v, k): [] for v in vals for k in ("detect", "step")}
 for _ in range(3):
     pipe(images)
@@ -34,7 +34,7 @@ for rd in range(6):
             runner.submit(images)
         torch.cuda.synchronize()
         res[(v, "step")].append((time.perf_counter() - t0) / 8 * 1e3)
-yvhip.set_option("conv_dma", 2)
+yvhip.set_option("conv_dma", 8)
 for v in vals:
     d, s = sorted(res[(v, "detect")]), sorted(res[(v, "step")])
     print(f"conv_dma={v}: detect stage alone median {d[3]:.3f} ms (min {d[0]:.3f})   pipelined step median {s[3]:.3f} ms (min {s[0]:.3f})")

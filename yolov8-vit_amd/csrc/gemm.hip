@@ -2418,7 +2418,7 @@ bool epi_can_stage(const GemmArgs& g) {
     return true;
 }
 
-int g_opt_conv_dma = 2;             // convolutions with 64-aligned input channels on the LDS-DMA structure ("conv_dma": 0 off, 1..4 see dispatch)
+int g_opt_conv_dma = 8;             // convolutions with 64-aligned input channels on the LDS-DMA structure ("conv_dma": 0 off, 1..8 see dispatch)
 
 template <int BN, int WM, int WN, int ST>
 int launch_cdma(GemmArgs& g, hipStream_t st) {
@@ -2448,13 +2448,24 @@ int dispatch(GemmArgs& g, hipStream_t st) {
             g.splitk <= 1 && !g.m_dev && (g.K % BK) == 0)
         {
             // conv_dma: 1 = two stages (128-wide tiles for Cout > 64), 2 = three stages, 64-wide tiles (two workgroups per CU, four K
-            // steps in flight per CU), 3 = three stages, 128-wide tiles (one workgroup per CU), 4 = four stages, 64-wide tiles
+            // steps in flight per CU), 3 = three stages, 128-wide tiles (one workgroup per CU), 4 = four stages, 64-wide tiles,
+            // 5 .. 8 mixtures.  Shipped: 8 = three stages / 64-wide, except the 128-channel layers of the large maps (>= 100 k output
+            // pixels: the 80 x 80 head convolution at batch 32), which read their pixels once on two-stage 128-wide tiles (70 -> 57 us
+            // alone; detect stage 1.175 -> 1.163 ms, YOLOv8m + ViT-L/16 1,376 -> 1,397 images/s; tools/conv_dma_ab.py)
             if (g_opt_conv_dma == 2) return launch_cdma<64, 4, 1, 3>(g, st);
             if (g_opt_conv_dma == 3) return g.N > 64 ? launch_cdma<128, 2, 2, 3>(g, st) : launch_cdma<64, 4, 1, 3>(g, st);
             if (g_opt_conv_dma == 4) return launch_cdma<64, 4, 1, 4>(g, st);
             if (g_opt_conv_dma == 5) {      // by reduction depth: deep K (>= 1024) three stages / 64-wide, shallow K two stages
                 if (g.K >= 1024) return launch_cdma<64, 4, 1, 3>(g, st);
                 return g.N > 64 ? launch_cdma<128, 2, 2, 2>(g, st) : launch_cdma<64, 4, 1, 2>(g, st);
+            }
+            if (g_opt_conv_dma == 7) {      // by rows: the large maps (>= 100 k output pixels) two stages, 128-wide where Cout allows
+                if (g.M >= 100000) return g.N > 64 ? launch_cdma<128, 2, 2, 2>(g, st) : launch_cdma<64, 4, 1, 2>(g, st);
+                return launch_cdma<64, 4, 1, 3>(g, st);
+            }
+            if (g_opt_conv_dma == 8) {      // as 7, only the 128-wide layers of the large maps
+                if (g.M >= 100000 && g.N > 64) return launch_cdma<128, 2, 2, 2>(g, st);
+                return launch_cdma<64, 4, 1, 3>(g, st);
             }
             if (g_opt_conv_dma == 6) {      // as 5, but 64-wide tiles everywhere
                 return g.K >= 1024 ? launch_cdma<64, 4, 1, 3>(g, st) : launch_cdma<64, 4, 1, 2>(g, st);
