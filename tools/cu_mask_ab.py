@@ -41,6 +41,12 @@ for spec in os.environ.get("SPECS", "48:block,48:rr,64:block,64:rr,32:rr").split
     else:                                  # every (256 / k)-th CU
         det_bits = sorted({int(i * 256 / k) for i in range(k)})
     cls_bits = [b for b in range(256) if b not in set(det_bits)]
+    if layout == "detonly":                # bit i = XCC i % 8, CU i / 8 (tools/cu_mask_probe.hip): the first k / 8 CUs of every XCC
+        det_bits = list(range(k))
+        r = PipelinedRunner(pipe, split_classifier=True)
+        r.s_det = masked_stream(det_bits)
+        variants.append((f"detector masked to {k} CUs, classifier unmasked", r))
+        continue
     r = PipelinedRunner(pipe, split_classifier=True, gemm_cus=len(cls_bits))
     r.s_det = masked_stream(det_bits)
     r.s_cls = masked_stream(cls_bits)
