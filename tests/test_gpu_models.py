@@ -280,14 +280,15 @@ def test_c2f_fused_equals_layer_by_layer(c, n, B, H, W):
     assert differ <= a.numel() // 50
 
 
-def test_yolo_engine_fused_c2f_vs_layer_by_layer():
-    """The detector with its backbone C2f blocks fused (model.2, model.4 of YOLOv8n) against the same engine running them
-    layer by layer: raw head outputs within the bf16 noise of a few re-rounded intermediates."""
+@pytest.mark.parametrize("scale", ["n", "s"])
+def test_yolo_engine_fused_c2f_vs_layer_by_layer(scale):
+    """The detector with its backbone C2f blocks fused (model.2, model.4 of YOLOv8n; model.2 of YOLOv8s: c = 32, n = 1) against
+    the same engine running them layer by layer: raw head outputs within the bf16 noise of a few re-rounded intermediates."""
     from yvhip import engines
-    sd = oy.init_state("n", 5, seed=7)
+    sd = oy.init_state(scale, 5, seed=7)
     g = torch.Generator().manual_seed(3)
     img = torch.randint(0, 256, (2, 320, 320, 3), generator=g, dtype=torch.uint8).to(DEV)
-    eng = engines.YoloEngine(sd, "n", 5, 320)
+    eng = engines.YoloEngine(sd, scale, 5, 320)
     assert eng.fused_c2f
     box_f, cls_f = eng.forward_raw(img)
     f2, f4 = eng._buffers(2)["out"][2].clone(), eng._buffers(2)["out"][4].clone()

@@ -352,3 +352,19 @@ def test_download_images_returns_bgr_like_cv2(monkeypatch, tmp_path):
     assert arr.shape == (4, 5, 3) and arr[0, 0].tolist() == [50, 100, 200]
     path = uu.download_images("http://host/x.png", str(tmp_path), save_flag=True)
     assert os.path.exists(path) and np.array_equal(np.asarray(Image.open(path).convert("RGB")), rgb)
+
+
+def test_yv_options_environment_knob():
+    """YV_OPTIONS="key=value,..." is applied through yv_set_option when the package is imported (A/B runs of an unmodified
+    bench.py); an unknown key must fail loudly instead of being ignored."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import yvhip; "
+            "print(yvhip.get_option('conv_dma'), yvhip.get_option('wgrad_split'))" % os.path.join(root, "yolov8-vit_amd"))
+    ok = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, YV_OPTIONS="conv_dma=2, wgrad_split=3"),
+                        capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-500:]
+    assert ok.stdout.split()[-2:] == ["2", "3"]
+    bad = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, YV_OPTIONS="no_such_option=1"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "yv_set_option" in bad.stderr
